@@ -1,0 +1,128 @@
+/* CPU restatement of the reference's proximal step -- TEST INFRASTRUCTURE ONLY
+ * (checker for the HIP kernel and the cpu_baseline leg of bench.py; the product
+ * never links or loads this).
+ *
+ * Restates /root/reference/lib/models.py:106-111:
+ *     n  = sqrt(sum(pow(Ws, 2), dim=2, keepdim=True))
+ *     Ws = Ws / clamp(n, min=1e-16)
+ *     Ws = Ws * clamp(n - t, min=0)
+ * with the arithmetic of the reference's CPU path spelled out so the result is
+ * the same bits on any host:
+ *   - pow(w,2) = w*w rounded to fp32; the row sum in the order of torch 2.10's
+ *     CPU kernel (see row_sumsq below);
+ *   - sqrt = Intel MKL VML vmsSqrt(HA) as torch 2.10 calls it on an AVX-512
+ *     host: y = rsqrt14(x); s = x*y; h = y/2; r = fma(fma(-s,s,x), h, s), with
+ *     rsqrt14 restated from a table (tools/gen_rsqrt14_table.c);
+ *   - divide and multiply correctly rounded, two roundings per element.
+ * Pinned by tests/golden/prox_vectors.npz and the pre_prox/post Ws pairs of
+ * every tests/golden/c*.npz (all recorded from the real reference).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared oracle/prox_oracle.c -o oracle/_build/libprox_oracle.so -lm
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* VRSQRT14SS restated.  tab: 65536 uint16 (tools/gen_rsqrt14_table.c). */
+float oivae_oracle_rsqrt14(float x, const uint16_t* tab) {
+  uint32_t u = f2u(x);
+  if (x != x) return x;
+  if ((u << 1) == 0) return u2f((u & 0x80000000u) | 0x7f800000u); /* +-0 -> +-inf */
+  if (u >> 31) return u2f(0xffc00000u);                            /* negative -> NaN */
+  if (u == 0x7f800000u) return 0.0f;
+  int e = (int)(u >> 23) - 127;
+  uint32_t m = u & 0x7fffffu;
+  if ((u >> 23) == 0) { /* denormal: normalise */
+    e = -126;
+    while (!(m & 0x800000u)) { m <<= 1; e--; }
+    m &= 0x7fffffu;
+  }
+  int par = e & 1;          /* x = 2^(e-par) * [1,4) */
+  int half = (e - par) / 2; /* exact: e-par is even */
+  if (par == 0 && m == 0) return ldexpf(1.0f, -half);
+  uint32_t frac = tab[par * 32768 + (m >> 8)];
+  float r = u2f((126u << 23) | (frac << 7)); /* in [0.5,1) */
+  return ldexpf(r, -half);
+}
+
+/* MKL VML vmsSqrt (HA) on AVX-512 as torch.sqrt reaches it. */
+float oivae_oracle_mkl_sqrtf(float x, const uint16_t* tab) {
+  if (x != x || x == 0.0f || x == INFINITY) return x;
+  if (x < 0.0f) return u2f(0xffc00000u);
+  /* Below 2^-104 the residual fma would go denormal; MKL rescales by an even
+   * power of two there (any even power >= 2^24 reproduces it, denormal inputs
+   * included), i.e. the formula is evaluated free of exponent-range effects. */
+  float back = 1.0f;
+  if (x < 0x1p-100f) { x *= 0x1p64f; back = 0x1p-32f; }
+  float y = oivae_oracle_rsqrt14(x, tab);
+  float s = x * y;
+  float h = 0.5f * y;
+  float d = fmaf(-s, s, x);
+  return fmaf(d, h, s) * back;
+}
+
+void oivae_oracle_mkl_sqrtf_array(const float* in, float* out, long n, const uint16_t* tab) {
+  for (long i = 0; i < n; i++) out[i] = oivae_oracle_mkl_sqrtf(in[i], tab);
+}
+
+void oivae_oracle_rsqrt14_array(const float* in, float* out, long n, const uint16_t* tab) {
+  for (long i = 0; i < n; i++) out[i] = oivae_oracle_rsqrt14(in[i], tab);
+}
+
+/* sum_h w[h]^2 in torch 2.10's CPU order for a contiguous fp32 inner dim
+ * (aten SumKernel: vectorized_inner_sum / scalar_inner_sum, 8-lane vectors,
+ * 4 interleaved accumulators).  H < 512 (no cascade step yet). */
+float oivae_oracle_row_sumsq(const float* w, int H) {
+  if (H < 8) {
+    float p[4] = {0, 0, 0, 0};
+    int nq = H / 4;
+    for (int i = 0; i < nq; i++)
+      for (int k = 0; k < 4; k++) p[k] = p[k] + w[4 * i + k] * w[4 * i + k];
+    for (int i = nq * 4; i < H; i++) p[0] = p[0] + w[i] * w[i];
+    for (int k = 1; k < 4; k++) p[0] = p[0] + p[k];
+    return p[0];
+  }
+  float P[4][8];
+  memset(P, 0, sizeof(P));
+  int V = H / 8, nq = V / 4;
+  for (int i = 0; i < nq; i++)
+    for (int k = 0; k < 4; k++)
+      for (int l = 0; l < 8; l++) { float a = w[(4 * i + k) * 8 + l]; P[k][l] = P[k][l] + a * a; }
+  for (int i = nq * 4; i < V; i++)
+    for (int l = 0; l < 8; l++) { float a = w[i * 8 + l]; P[0][l] = P[0][l] + a * a; }
+  for (int k = 1; k < 4; k++)
+    for (int l = 0; l < 8; l++) P[0][l] = P[0][l] + P[k][l];
+  float acc = 0.0f;
+  for (int i = V * 8; i < H; i++) acc = acc + w[i] * w[i];
+  for (int l = 0; l < 8; l++) acc = acc + P[0][l];
+  return acc;
+}
+
+/* In-place proximal step over Ws[rows][H]; mask[r] = 1 iff the row is all zero
+ * afterwards; norms_out (optional) receives the pre-update row norms.
+ * Returns 0, or 1 if H is outside the pinned range. */
+int oivae_oracle_prox_f32(float* Ws, long rows, int H, float t, const uint16_t* tab,
+                          uint8_t* mask, float* norms_out) {
+  if (H < 1 || H >= 512) return 1;
+  for (long r = 0; r < rows; r++) {
+    float* w = Ws + r * (long)H;
+    float n = oivae_oracle_mkl_sqrtf(oivae_oracle_row_sumsq(w, H), tab);
+    float den = n < 1e-16f ? 1e-16f : n;   /* clamp(n, min=1e-16); NaN passes through */
+    if (n != n) den = n;
+    float sc = n - t;
+    if (sc < 0.0f) sc = 0.0f;              /* clamp(n - t, min=0); NaN passes through */
+    int allzero = 1;
+    for (int h = 0; h < H; h++) {
+      float v = w[h] / den;
+      v = v * sc;
+      w[h] = v;
+      if (!(v == 0.0f)) allzero = 0;
+    }
+    if (mask) mask[r] = (uint8_t)allzero;
+    if (norms_out) norms_out[r] = n;
+  }
+  return 0;
+}
