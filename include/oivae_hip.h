@@ -1,0 +1,182 @@
+/* oivae_hip.h -- C ABI of the MI355X (gfx950) oi-VAE training-step engine.
+ *
+ * The reference (samuela/oi-vae) is pure Python on PyTorch and has no FFI of its
+ * own; its drop-in boundary is the object protocol consumed by OIVAE.step
+ * (/root/reference/lib/oivae.py:42-90).  This header is the native boundary that
+ * the host-side mirror of that protocol (oi_vae_amd/, Python + ctypes) binds.
+ * Every entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *   - plain C types only: device pointers (fp32 unless said otherwise), sizes,
+ *     and the HIP stream as an opaque `void*` (a hipStream_t; NULL = the null
+ *     stream).  Pointers are borrowed for the duration of the call.
+ *   - every call is asynchronous on `stream` and returns 0 on success or a
+ *     nonzero OIVAE_E_* code; oivae_last_error() gives the message (per thread).
+ *   - no entry point allocates or frees device memory, except oivae_init, which
+ *     uploads a 128 KiB constant table once per device.
+ *   - row-major everywhere.  B = batch rows, S = Monte-Carlo samples,
+ *     N = S*B decoder rows (sample-major: row n = s*B + b, lib/oivae.py:53),
+ *     K = latent dim, G = groups, H = group input dim, M = generator hidden
+ *     width (0 when the generator has no hidden layer), D = sum of group dims.
+ */
+#ifndef OIVAE_HIP_H
+#define OIVAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  OIVAE_OK = 0,
+  OIVAE_E_ARG = 1,        /* bad argument (null pointer, negative size, ...) */
+  OIVAE_E_SHAPE = 2,      /* shape outside what the kernels support */
+  OIVAE_E_HIP = 3,        /* a HIP runtime call failed */
+  OIVAE_E_WORKSPACE = 4,  /* workspace too small */
+  OIVAE_E_NOINIT = 5      /* oivae_init not called for the current device */
+};
+
+/* generator mu_net architectures seen in the reference's scripts */
+enum {
+  OIVAE_GEN_LINEAR = 0,       /* Linear(H, D_g)                bars_data_oivae.py:97, meg_oi_vae.py:178 */
+  OIVAE_GEN_TANH_LINEAR = 1,  /* Tanh -> Linear(H, D_g)        mo_mo_mocap_oivae.py:203-207 */
+  OIVAE_GEN_MLP = 2           /* Linear(H,M) -> Tanh -> Linear(M, D_g)   (BASELINE.json "2-layer generators") */
+};
+
+/* Shapes of one model.  group_off is a DEVICE array of G+1 int32 prefix sums of
+ * the group output dims (group g owns columns [group_off[g], group_off[g+1]) of
+ * X); max_group_dim is the largest of them. */
+typedef struct {
+  int32_t D, K, G, H, M;
+  int32_t gen_type;
+  int32_t max_group_dim;
+  int32_t uniform_group_dim;  /* D_g when all groups are equal, else 0 */
+  const int32_t* group_off;
+} oivae_shape_t;
+
+/* One set of per-parameter device arrays: used for the parameters and, with the
+ * same layout, for their gradients.
+ *   enc_Wmu,enc_Wsig [K,D]; enc_bmu,enc_bsig [K]      (nn.Linear [out,in], bars_data_oivae.py:66-87)
+ *   gen_W1 [G,M,H]; gen_b1 [G,M]                      (MLP only)
+ *   gen_W2 [D,Hin] = the G per-group Linear weights [D_g,Hin] stacked on rows,
+ *   gen_b2 [D]       Hin = M for MLP else H           (bars_data_oivae.py:96-97)
+ *   log_sigma [D]                                     (bars_data_oivae.py:92-95)
+ *   Ws [G,K,H]                                        (lib/models.py:86-89) */
+typedef struct {
+  float *enc_Wmu, *enc_bmu, *enc_Wsig, *enc_bsig;
+  float *gen_W1, *gen_b1, *gen_W2, *gen_b2;
+  float *log_sigma;
+  float *Ws;
+} oivae_tensors_t;
+
+/* Scalars of one step, written on the device by oivae_finalize_f32
+ * (lib/oivae.py:81-90, all pre-update values). */
+typedef struct {
+  float z_kl, loglik_term, logprob_theta, logprob_W, loss, elbo;
+  float penalty;   /* sum of row norms, lib/models.py:113-114 */
+  float pad;
+} oivae_scalars_t;
+
+/* ---- library ---------------------------------------------------------- */
+int oivae_init(int device);               /* idempotent; uploads the rsqrt14 table */
+const char* oivae_last_error(void);
+const char* oivae_version(void);
+
+/* Bytes of workspace the step entry points need for these shapes and N rows. */
+int64_t oivae_workspace_bytes(const oivae_shape_t* shape, int64_t B, int32_t S);
+
+/* ---- proximal step ------------------------------------------------------
+ * Replaces BayesianGroupLassoGenerator.proximal_step, lib/models.py:106-111:
+ * in place, for every row of Ws viewed as [rows, H]:
+ *   n = sqrt(sum_h w^2); w = (w / max(n,1e-16)) * max(n - t, 0)
+ * bit for bit as the reference's CPU path computes it (torch row-sum order,
+ * MKL-VML square root, two roundings per element).  zero_mask[r] (optional)
+ * = 1 iff the row is all zeros afterwards; row_norms (optional) = n. */
+int oivae_prox_f32(float* Ws, int64_t rows, int32_t H, float t,
+                   uint8_t* zero_mask, float* row_norms, void* stream);
+
+/* SGD(momentum=0) on Ws fused with the proximal step: w -= lr*g, then prox.
+ * Replaces optimizer_Ws.step() (bars_data_oivae.py:241-244, torch.optim.SGD:
+ * w = fma(-lr, g, w) as the CPU kernel rounds it) followed by
+ * proximal_step (lib/oivae.py:76-79).  do_prox = 0 skips the threshold
+ * (lam == 0, lib/oivae.py:78). */
+int oivae_sgd_prox_f32(float* Ws, const float* dWs, int64_t rows, int32_t H,
+                       float lr, float t, int32_t do_prox,
+                       uint8_t* zero_mask, float* row_norms, void* stream);
+
+/* ---- encoder forward + reparameterisation + KL ---------------------------
+ * Replaces inference_model(X) (lib/models.py:15-16 with the heads of
+ * bars_data_oivae.py:66-87), KL_Normals (lib/utils.py:9-18, lib/oivae.py:50)
+ * and the S calls of Normal.sample (lib/distributions.py:36-38, lib/oivae.py:53):
+ *   mu_q = X Wmu^T + bmu;  ea = exp(X Wsig^T + bsig);  sig_q = ea*c + sig_off
+ *   z[s*B+b] = mu_q[b] + sig_q[b]*eps[s,b]
+ *   kl partial sums of -0.5 + (sig_q^2 + (mu_q-mu_p)^2)/(2 sig_p^2) + log sig_p - log sig_q
+ * prior_mu/prior_sigma: [prior_rows, K] with prior_rows 1 (broadcast) or B.
+ * Outputs mu_q, sig_q, ea [B,K]; z [S*B,K]. KL partials go to the workspace. */
+int oivae_encoder_fwd_f32(const oivae_shape_t* shape, const oivae_tensors_t* params,
+                          const float* X, int64_t B, int32_t S, const float* eps,
+                          float c, float sig_off,
+                          const float* prior_mu, const float* prior_sigma, int32_t prior_rows,
+                          float* mu_q, float* sig_q, float* ea, float* z,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- grouped decoder forward + backward ----------------------------------
+ * Replaces generative_model(z_sample).logprob(Xrep) (lib/models.py:91-95,
+ * lib/distributions.py:40-45,88-93, lib/oivae.py:54-59) and the decoder half
+ * of loss.backward() (lib/oivae.py:75): per group g
+ *   h = z Ws[g]; mu = mu_net_g(h); sigma = exp(log_sigma_g) + gen_sig_off
+ *   loglik partial sums of -0.5*LOG2PI - log sigma - 0.5*((x - mu)/sigma)^2
+ * and the gradients of loss = -loglik/(S*B) w.r.t. gen_W1,gen_b1,gen_W2,gen_b2,
+ * log_sigma, Ws (written to `grads`, complete: not accumulated) and w.r.t. z
+ * (dz [S*B,K], overwritten).  Neither mu nor sigma [N,D] is materialised; X is
+ * indexed as X[n mod B] instead of being repeated (lib/oivae.py:54).
+ * The encoder entries of `grads` are not touched. */
+int oivae_decoder_fwd_bwd_f32(const oivae_shape_t* shape, const oivae_tensors_t* params,
+                              const oivae_tensors_t* grads,
+                              const float* X, int64_t B, int32_t S, const float* z,
+                              float gen_sig_off, float* dz,
+                              void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- encoder backward -----------------------------------------------------
+ * Replaces the encoder half of loss.backward() (lib/oivae.py:75):
+ *   dmu_q = sum_s dz[s] + (mu_q - mu_p)/sig_p^2 / B
+ *   dsig_q = sum_s dz[s]*eps[s] + (sig_q/sig_p^2 - 1/sig_q) / B
+ *   da = dsig_q * c * ea
+ *   dWmu = dmu_q^T X, dbmu = colsum(dmu_q), dWsig = da^T X, dbsig = colsum(da)
+ * written to the encoder entries of `grads`. */
+int oivae_encoder_bwd_f32(const oivae_shape_t* shape, const oivae_tensors_t* grads,
+                          const float* X, int64_t B, int32_t S, const float* eps, float c,
+                          const float* prior_mu, const float* prior_sigma, int32_t prior_rows,
+                          const float* mu_q, const float* sig_q, const float* ea,
+                          const float* dz,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- weight prior, group-lasso penalty, scalars ----------------------------
+ * Replaces NormalPriorTheta.logprob (lib/oivae.py:15-23): sum over every
+ * generator mu_net parameter (gen_W1,gen_b1,gen_W2,gen_b2) of
+ * -0.5*LOG2PI - log(sigma_theta) - 0.5*(theta/sigma_theta)^2, adds its gradient
+ * theta/sigma_theta^2 to `grads`; group_lasso_penalty (lib/models.py:113-114);
+ * and the combination of lib/oivae.py:50,55-59,65,70-71 into `out` (device):
+ *   z_kl = kl/B; loglik_term = ll/S/B; logprob_W = -lam*penalty;
+ *   loss = -(-z_kl + loglik_term + logprob_theta); elbo = -loss + logprob_W. */
+int oivae_finalize_f32(const oivae_shape_t* shape, const oivae_tensors_t* params,
+                       const oivae_tensors_t* grads, int64_t B, int32_t S,
+                       float sigma_theta, float lam, oivae_scalars_t* out,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- Adam --------------------------------------------------------------------
+ * One fused Adam update over a flat fp32 buffer: replaces optimizer.step() for
+ * torch.optim.Adam with default options (bars_data_oivae.py:233-239):
+ *   m = m + (1-b1)(g-m); v = b2*v + (1-b2) g^2
+ *   p -= (lr/(1-b1^step)) * m / (sqrt(v)/sqrt(1-b2^step) + eps)
+ * grad_scale multiplies g first (1/world_size when gradients were summed
+ * across ranks). */
+int oivae_adam_f32(float* p, const float* g, float* m, float* v, int64_t n,
+                   float lr, float beta1, float beta2, float eps, int32_t step,
+                   float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OIVAE_HIP_H */

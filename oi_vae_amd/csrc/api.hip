@@ -1,0 +1,297 @@
+// Library plumbing of the oi-VAE HIP engine: errors, init, workspace carving,
+// the fused Adam update and the scalar finalisation.
+#include "common.h"
+
+#include <string.h>
+#include <mutex>
+
+// The rsqrt14 table (tools/gen_rsqrt14_table.c) is linked into the library.
+#ifndef OIVAE_RSQRT14_BIN
+#error "build with -DOIVAE_RSQRT14_BIN=\"/abs/path/to/rsqrt14_u16.bin\""
+#endif
+__asm__(
+    ".section .rodata\n"
+    ".balign 16\n"
+    ".global oivae_rsqrt14_blob\n"
+    "oivae_rsqrt14_blob:\n"
+    ".incbin \"" OIVAE_RSQRT14_BIN "\"\n"
+    ".global oivae_rsqrt14_blob_end\n"
+    "oivae_rsqrt14_blob_end:\n"
+    ".previous\n");
+extern "C" const unsigned char oivae_rsqrt14_blob[];
+extern "C" const unsigned char oivae_rsqrt14_blob_end[];
+
+namespace oivae {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+constexpr int kMaxDevices = 64;
+static uint16_t* g_tab[kMaxDevices] = {nullptr};
+static std::mutex g_init_mu;
+
+const uint16_t* rsqrt14_table_device() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  return g_tab[dev];
+}
+
+int check_shape(const oivae_shape_t* s) {
+  if (!s) return fail(OIVAE_E_ARG, "null shape");
+  if (s->D < 1 || s->K < 1 || s->G < 1 || s->H < 1 || s->M < 0)
+    return fail(OIVAE_E_SHAPE, "bad dims D=%d K=%d G=%d H=%d M=%d", s->D, s->K, s->G, s->H, s->M);
+  if (s->gen_type < 0 || s->gen_type > 2) return fail(OIVAE_E_SHAPE, "bad gen_type %d", s->gen_type);
+  if (s->gen_type == OIVAE_GEN_MLP && s->M < 1) return fail(OIVAE_E_SHAPE, "MLP generator needs M >= 1");
+  if (s->gen_type != OIVAE_GEN_MLP && s->M != 0) return fail(OIVAE_E_SHAPE, "M must be 0 without a hidden layer");
+  if (!s->group_off) return fail(OIVAE_E_ARG, "null group_off");
+  if (s->max_group_dim < 1 || s->max_group_dim > s->D) return fail(OIVAE_E_SHAPE, "bad max_group_dim");
+  if (s->K > 512) return fail(OIVAE_E_SHAPE, "K=%d > 512 unsupported", s->K);
+  return OIVAE_OK;
+}
+
+int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, int64_t bytes,
+                    Workspace* w) {
+  const int64_t N = B * (int64_t)S;
+  DecPlan plan = plan_decoder(s, N);
+  DecLayout L = dec_layout(s);
+  char* p = static_cast<char*>(base);
+  int64_t off = 0;
+  auto take = [&](int64_t nbytes) -> char* {
+    char* r = p ? p + off : nullptr;
+    off += align_up(nbytes, 256);
+    return r;
+  };
+  w->n_kl = kMaxPartials;
+  w->kl_part = reinterpret_cast<double*>(take(sizeof(double) * kMaxPartials));
+  w->n_ll = kMaxPartials;
+  w->ll_part = reinterpret_cast<double*>(take(sizeof(double) * kMaxPartials));
+  w->n_theta = 1024;
+  w->theta_part = reinterpret_cast<double*>(take(sizeof(double) * 1024));
+  w->n_pen = 1024;
+  w->pen_part = reinterpret_cast<double*>(take(sizeof(double) * 1024));
+  w->dpre = reinterpret_cast<float*>(take(sizeof(float) * B * 2 * s.K));
+  w->n_chunks = plan.chunks;
+  w->p_dec = L.total;
+  w->slab = reinterpret_cast<float*>(take(plan.chunks > 1 ? sizeof(float) * L.total * plan.chunks : 0));
+  w->total_bytes = off;
+  if (p && bytes < off)
+    return fail(OIVAE_E_WORKSPACE, "workspace too small: %lld < %lld bytes", (long long)bytes, (long long)off);
+  return OIVAE_OK;
+}
+
+// ---- Adam ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   int64_t n, float one_minus_b1, float b2,
+                                                   float one_minus_b2, float step_size,
+                                                   float inv_bc2_sqrt, float eps, float gscale) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float gi = g[i] * gscale;
+    float mi = m[i], vi = v[i];
+    mi = mi + one_minus_b1 * (gi - mi);           // exp_avg.lerp_(grad, 1-beta1)
+    vi = b2 * vi + one_minus_b2 * gi * gi;        // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+// ---- weight prior + penalty + scalar combination ---------------------------------
+// theta prior over a flat range: sum of theta^2 (double) and grad += theta/sigma^2
+__global__ __launch_bounds__(256) void theta_prior_kernel(const float* __restrict__ th,
+                                                          float* __restrict__ gr, int64_t n,
+                                                          float inv_var, double* __restrict__ part) {
+  __shared__ double sm[256];
+  double acc = 0.0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float x = th[i];
+    acc += (double)x * (double)x;
+    gr[i] = gr[i] + x * inv_var;
+  }
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+
+__global__ __launch_bounds__(256) void penalty_kernel(const float* __restrict__ Ws, int64_t rows, int H,
+                                                      double* __restrict__ part) {
+  __shared__ double sm[256];
+  double acc = 0.0;
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; r < rows; r += stride) {
+    const float* w = Ws + r * H;
+    float s = 0.f;
+    for (int h = 0; h < H; ++h) s += w[h] * w[h];
+    acc += (double)sqrtf(s);
+  }
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+
+// sums the partial arrays in index order (deterministic) and writes the scalars
+__global__ __launch_bounds__(256) void finalize_kernel(const double* kl, int n_kl, const double* ll, int n_ll,
+                                                       const double* th, int n_th, const double* pen, int n_pen,
+                                                       double n_theta_elems, float sigma_theta, float lam,
+                                                       float B, float S, oivae_scalars_t* out) {
+  __shared__ double sm[4][256];
+  const double* src[4] = {kl, ll, th, pen};
+  const int cnt[4] = {n_kl, n_ll, n_th, n_pen};
+  for (int q = 0; q < 4; ++q) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < cnt[q]; i += 256) a += src[q][i];
+    sm[q][threadIdx.x] = a;
+  }
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+      for (int q = 0; q < 4; ++q) sm[q][threadIdx.x] += sm[q][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float kl_sum = (float)sm[0][0];
+    const float ll_sum = (float)sm[1][0];
+    const double th_sq = sm[2][0];
+    const float penalty = (float)sm[3][0];
+    // lib/oivae.py:15-23: sum of -0.5*LOG2PI - log(sigma) - 0.5*(theta/sigma)^2
+    const double st = (double)sigma_theta;
+    const float lp_theta = (float)(n_theta_elems * (-0.5 * (double)kLog2Pi - log(st)) - 0.5 * th_sq / (st * st));
+    const float z_kl = kl_sum / B;                 // lib/oivae.py:50
+    const float loglik = (ll_sum / S) / B;         // lib/oivae.py:55-59
+    const float lp_W = -lam * penalty;             // lib/oivae.py:65
+    const float loss = -1.0f * (-z_kl + loglik + lp_theta);  // lib/oivae.py:70
+    const float elbo = -loss + lp_W;               // lib/oivae.py:71
+    out->z_kl = z_kl;
+    out->loglik_term = loglik;
+    out->logprob_theta = lp_theta;
+    out->logprob_W = lp_W;
+    out->loss = loss;
+    out->elbo = elbo;
+    out->penalty = penalty;
+    out->pad = 0.f;
+  }
+}
+
+}  // namespace oivae
+
+using namespace oivae;
+
+extern "C" const char* oivae_last_error(void) { return g_err; }
+extern "C" const char* oivae_version(void) { return "oivae_hip 0.1 (gfx950)"; }
+
+extern "C" int oivae_init(int device) {
+  if (device < 0 || device >= kMaxDevices) return fail(OIVAE_E_ARG, "oivae_init: bad device %d", device);
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  if (g_tab[device]) return OIVAE_OK;
+  const size_t nbytes = (size_t)(oivae_rsqrt14_blob_end - oivae_rsqrt14_blob);
+  if (nbytes != 65536 * sizeof(uint16_t))
+    return fail(OIVAE_E_ARG, "oivae_init: embedded rsqrt14 table has %zu bytes", nbytes);
+  int prev = -1;
+  OIVAE_HIP_CHECK(hipGetDevice(&prev));
+  OIVAE_HIP_CHECK(hipSetDevice(device));
+  uint16_t* d = nullptr;
+  OIVAE_HIP_CHECK(hipMalloc(&d, nbytes));
+  OIVAE_HIP_CHECK(hipMemcpy(d, oivae_rsqrt14_blob, nbytes, hipMemcpyHostToDevice));
+  g_tab[device] = d;
+  OIVAE_HIP_CHECK(hipSetDevice(prev));
+  return OIVAE_OK;
+}
+
+extern "C" int64_t oivae_workspace_bytes(const oivae_shape_t* shape, int64_t B, int32_t S) {
+  if (check_shape(shape) != OIVAE_OK || B < 1 || S < 1) return -1;
+  Workspace w;
+  carve_workspace(*shape, B, S, nullptr, 0, &w);
+  return w.total_bytes;
+}
+
+extern "C" int oivae_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                              float beta1, float beta2, float eps, int32_t step, float grad_scale,
+                              void* stream) {
+  if (!p || !g || !m || !v || n < 0 || step < 1) return fail(OIVAE_E_ARG, "oivae_adam_f32: bad argument");
+  if (n == 0) return OIVAE_OK;
+  // scalar prep in double like torch's Python-side _single_tensor_adam
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                     1.0f - beta1, beta2, 1.0f - beta2, step_size, inv_bc2_sqrt, eps, grad_scale);
+  OIVAE_LAUNCH_CHECK();
+  return OIVAE_OK;
+}
+
+extern "C" int oivae_finalize_f32(const oivae_shape_t* shape, const oivae_tensors_t* params,
+                                  const oivae_tensors_t* grads, int64_t B, int32_t S, float sigma_theta,
+                                  float lam, oivae_scalars_t* out, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+  if (int rc = check_shape(shape)) return rc;
+  if (!params || !grads || !out || !workspace || B < 1 || S < 1)
+    return fail(OIVAE_E_ARG, "oivae_finalize_f32: bad argument");
+  if (!(sigma_theta > 0.f)) return fail(OIVAE_E_ARG, "oivae_finalize_f32: sigma_theta must be > 0");
+  Workspace w;
+  if (int rc = carve_workspace(*shape, B, S, workspace, workspace_bytes, &w)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const oivae_shape_t& s = *shape;
+  const int64_t hin = (s.gen_type == OIVAE_GEN_MLP) ? s.M : s.H;
+  // the four generator parameter arrays, each with a quarter of the partial slots
+  const float* th[4] = {params->gen_W1, params->gen_b1, params->gen_W2, params->gen_b2};
+  float* gr[4] = {grads->gen_W1, grads->gen_b1, grads->gen_W2, grads->gen_b2};
+  const int64_t cnt[4] = {s.gen_type == OIVAE_GEN_MLP ? (int64_t)s.G * s.M * s.H : 0,
+                          s.gen_type == OIVAE_GEN_MLP ? (int64_t)s.G * s.M : 0, (int64_t)s.D * hin,
+                          (int64_t)s.D};
+  OIVAE_HIP_CHECK(hipMemsetAsync(w.theta_part, 0, sizeof(double) * w.n_theta, st));
+  const float inv_var = 1.0f / (sigma_theta * sigma_theta);
+  double n_theta_elems = 0;
+  const int slots = w.n_theta / 4;
+  for (int q = 0; q < 4; ++q) {
+    if (cnt[q] == 0) continue;
+    if (!th[q] || !gr[q]) return fail(OIVAE_E_ARG, "oivae_finalize_f32: null generator tensor %d", q);
+    n_theta_elems += (double)cnt[q];
+    int64_t blocks = (cnt[q] + 255) / 256;
+    if (blocks > slots) blocks = slots;
+    hipLaunchKernelGGL(theta_prior_kernel, dim3((unsigned)blocks), dim3(256), 0, st, th[q], gr[q], cnt[q],
+                       inv_var, w.theta_part + q * slots);
+    OIVAE_LAUNCH_CHECK();
+  }
+  const int64_t rows = (int64_t)s.G * s.K;
+  int64_t pblocks = (rows + 255) / 256;
+  if (pblocks > w.n_pen) pblocks = w.n_pen;
+  OIVAE_HIP_CHECK(hipMemsetAsync(w.pen_part, 0, sizeof(double) * w.n_pen, st));
+  hipLaunchKernelGGL(penalty_kernel, dim3((unsigned)pblocks), dim3(256), 0, st, params->Ws, rows, s.H, w.pen_part);
+  OIVAE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, w.kl_part, w.n_kl, w.ll_part, w.n_ll,
+                     w.theta_part, w.n_theta, w.pen_part, w.n_pen, n_theta_elems, sigma_theta, lam,
+                     (float)B, (float)S, out);
+  OIVAE_LAUNCH_CHECK();
+  return OIVAE_OK;
+}

@@ -1,0 +1,86 @@
+// Shared host/device helpers of the oi-VAE HIP engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/oivae_hip.h"
+
+namespace oivae {
+
+// fp32 value of log(fp32(2*pi)) as the reference computes it
+// (/root/reference/lib/distributions.py:9).
+constexpr float kLog2Pi = 1.8378770351409912f;
+
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+#define OIVAE_HIP_CHECK(expr)                                                        \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess)                                                            \
+      return ::oivae::fail(OIVAE_E_HIP, "%s failed: %s (%s:%d)", #expr,              \
+                           hipGetErrorString(_e), __FILE__, __LINE__);               \
+  } while (0)
+
+#define OIVAE_LAUNCH_CHECK() OIVAE_HIP_CHECK(hipGetLastError())
+
+inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// Device pointer to the 65536-entry rsqrt14 table of the current device
+// (uploaded by oivae_init), or nullptr.
+const uint16_t* rsqrt14_table_device();
+
+// ---- workspace layout -------------------------------------------------------
+// One flat device buffer, carved identically by every entry point.
+struct Workspace {
+  // reduction partials (double), fixed slot counts
+  double* kl_part;      int32_t n_kl;      // one per encoder-forward block
+  double* ll_part;      int32_t n_ll;      // one per decoder block
+  double* theta_part;   int32_t n_theta;   // weight-prior partials
+  double* pen_part;     int32_t n_pen;     // penalty partials
+  float*  dpre;                            // [B, 2K] encoder pre-activation grads
+  float*  slab;         int32_t n_chunks;  // [n_chunks, P_dec] decoder grad partials (n_chunks > 1)
+  int64_t p_dec;                           // floats per decoder-grad slab
+  int64_t total_bytes;
+};
+
+constexpr int kMaxPartials = 16384;  // cap on per-kernel block counts that emit partials
+
+// sizes of the decoder parameter block, in floats, in slab order:
+// [gen_W1 | gen_b1 | gen_W2 | gen_b2 | log_sigma | Ws]
+struct DecLayout {
+  int64_t oW1, ob1, oW2, ob2, oLs, oWs, total;
+};
+
+inline DecLayout dec_layout(const oivae_shape_t& s) {
+  DecLayout L;
+  int64_t hin = (s.gen_type == OIVAE_GEN_MLP) ? s.M : s.H;
+  int64_t nW1 = (s.gen_type == OIVAE_GEN_MLP) ? (int64_t)s.G * s.M * s.H : 0;
+  int64_t nb1 = (s.gen_type == OIVAE_GEN_MLP) ? (int64_t)s.G * s.M : 0;
+  L.oW1 = 0;
+  L.ob1 = L.oW1 + nW1;
+  L.oW2 = L.ob1 + nb1;
+  L.ob2 = L.oW2 + (int64_t)s.D * hin;
+  L.oLs = L.ob2 + s.D;
+  L.oWs = L.oLs + s.D;
+  L.total = L.oWs + (int64_t)s.G * s.K * s.H;
+  return L;
+}
+
+// rows per decoder tile and number of row chunks for the generic decoder
+struct DecPlan {
+  int32_t R;        // rows per tile (32 or 64)
+  int32_t DC;       // output-column chunk
+  int32_t chunks;   // row chunks (grid.y)
+  int64_t lds_bytes;
+  bool mfma;        // fast path applies
+};
+
+DecPlan plan_decoder(const oivae_shape_t& s, int64_t N);
+int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, int64_t bytes,
+                    Workspace* out);
+int check_shape(const oivae_shape_t* s);
+
+}  // namespace oivae

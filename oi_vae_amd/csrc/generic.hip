@@ -1,0 +1,597 @@
+// Shape-generic kernels of the oi-VAE step (any K, H, M, ragged group dims).
+//
+// These are the correctness-first paths that serve the small, launch-bound
+// configurations (bars, mocap, MEG: SURVEY.md section 8 C1-C3, C5) and every shape
+// the MFMA fast paths (mfma_*.hip) do not cover.  All reductions that feed
+// parameter gradients run in a fixed order (per-block slabs, summed in index
+// order), so decoder and encoder weight gradients are reproducible run to run;
+// only dz, summed over groups with float atomics, is not.
+#include "common.h"
+
+namespace oivae {
+
+// ------------------------------------------------------------------------------
+// block reduction helper (double), result valid in thread 0
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_double(double v, double* sm /*[256]*/) {
+  sm[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+    __syncthreads();
+  }
+  return sm[0];
+}
+
+// ------------------------------------------------------------------------------
+// encoder forward: two linear heads + exp/affine + reparameterisation + KL
+// (lib/models.py:15-16, bars_data_oivae.py:66-87, lib/utils.py:9-18,
+//  lib/distributions.py:36-38)
+// ------------------------------------------------------------------------------
+constexpr int kEncRows = 16;   // batch rows per block
+constexpr int kEncDC = 256;    // X columns staged per step
+
+__global__ __launch_bounds__(256) void enc_fwd_generic(
+    const float* __restrict__ X, int64_t B, int D, int K, const float* __restrict__ Wmu,
+    const float* __restrict__ bmu, const float* __restrict__ Wsig, const float* __restrict__ bsig, int S,
+    const float* __restrict__ eps, float c, float sig_off, const float* __restrict__ prior_mu,
+    const float* __restrict__ prior_sigma, int prior_stride, float* __restrict__ mu_q,
+    float* __restrict__ sig_q, float* __restrict__ ea, float* __restrict__ z,
+    double* __restrict__ kl_part) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sX = reinterpret_cast<float*>(smem_raw);            // [kEncRows][kEncDC+1]
+  float* sOut = sX + kEncRows * (kEncDC + 1);                // [kEncRows][2K]
+  __shared__ double sred[256];
+  const int J = 2 * K;
+  const int tid = threadIdx.x;
+  const int r = tid >> 4, jj = tid & 15;
+  const int64_t b0 = (int64_t)blockIdx.x * kEncRows;
+  // output columns are processed 8*16 = 128 at a time
+  for (int jb = 0; jb < J; jb += 128) {
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    const float* wrow[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = jb + jj + 16 * q;
+      wrow[q] = (j < K) ? (Wmu + (int64_t)j * D) : (j < J ? Wsig + (int64_t)(j - K) * D : nullptr);
+    }
+    for (int d0 = 0; d0 < D; d0 += kEncDC) {
+      const int dn = min(kEncDC, D - d0);
+      __syncthreads();
+      for (int rr = 0; rr < kEncRows; ++rr) {
+        const int64_t b = b0 + rr;
+        if (tid < dn) sX[rr * (kEncDC + 1) + tid] = (b < B) ? X[b * D + d0 + tid] : 0.f;
+      }
+      __syncthreads();
+      const float* xr = sX + r * (kEncDC + 1);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (wrow[q]) {
+          const float* w = wrow[q] + d0;
+          float a = acc[q];
+          for (int dd = 0; dd < dn; ++dd) a = fmaf(xr[dd], w[dd], a);
+          acc[q] = a;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = jb + jj + 16 * q;
+      if (j < J) sOut[r * J + j] = acc[q];
+    }
+  }
+  __syncthreads();
+  double kl = 0.0;
+  for (int idx = tid; idx < kEncRows * K; idx += 256) {
+    const int rr = idx / K, k = idx - rr * K;
+    const int64_t b = b0 + rr;
+    if (b >= B) continue;
+    const float mu = sOut[rr * J + k] + bmu[k];
+    const float a = sOut[rr * J + K + k] + bsig[k];
+    const float e = expf(a);
+    const float sg = e * c + sig_off;
+    const float mp = prior_mu[(int64_t)b * prior_stride + k];
+    const float sp = prior_sigma[(int64_t)b * prior_stride + k];
+    const float dm = mu - mp;
+    kl += (double)(-0.5f + (sg * sg + dm * dm) / (2.f * sp * sp) + logf(sp) - logf(sg));
+    mu_q[b * K + k] = mu;
+    sig_q[b * K + k] = sg;
+    ea[b * K + k] = e;
+    for (int s = 0; s < S; ++s) {
+      const int64_t n = (int64_t)s * B + b;
+      z[n * K + k] = mu + sg * eps[n * K + k];
+    }
+  }
+  const double tot = block_sum_double(kl, sred);
+  if (tid == 0) kl_part[blockIdx.x] = tot;
+}
+
+// ------------------------------------------------------------------------------
+// grouped decoder forward + backward, generic shapes
+// (lib/models.py:91-95, lib/distributions.py:40-45,88-93, lib/oivae.py:54-59,75)
+// ------------------------------------------------------------------------------
+struct DecArgs {
+  int D, K, G, H, M, Hin, gen_type;
+  const int32_t* group_off;
+  const float *W1, *b1, *W2, *b2, *ls, *Ws;  // parameters
+  float *gW1, *gb1, *gW2, *gb2, *gls, *gWs;  // destinations of chunk 0
+  int64_t chunk_stride;                      // floats between chunks' destinations (0 if one chunk)
+  const float* X;
+  const float* z;
+  float* dz;
+  int64_t B, N;
+  float inv;          // 1/(S*B)
+  float sig_off;
+  int DC;             // output-column chunk
+  double* ll_part;
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void dec_generic(DecArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ double sred[256];
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x, chunk = blockIdx.y, nchunks = gridDim.y;
+  const int K = a.K, H = a.H, M = a.M, Hin = a.Hin, typ = a.gen_type, DC = a.DC;
+  const int off = a.group_off[g];
+  const int Dg = a.group_off[g + 1] - off;
+  const int HP = H | 1, HinP = Hin | 1;
+  // ---- carve LDS ----
+  float* p = reinterpret_cast<float*>(smem_raw);
+  float* sWs = p;  p += K * HP;
+  float* sW1 = p;  p += (typ == OIVAE_GEN_MLP) ? M * HP : 0;
+  float* sb1 = p;  p += (typ == OIVAE_GEN_MLP) ? M : 0;
+  float* sW2 = p;  p += DC * HinP;           // one column chunk of W2 at a time
+  float* sb2 = p;  p += DC;
+  float* sSig = p; p += DC;
+  float* sLogSig = p; p += DC;
+  float* sCoef = p; p += DC;
+  float* sz = p;   p += R * K;
+  float* sh = p;   p += R * H;
+  float* sact = (typ == OIVAE_GEN_LINEAR) ? sh : p;  p += (typ == OIVAE_GEN_LINEAR) ? 0 : R * Hin;
+  float* sdact = p; p += R * Hin;
+  float* sdh = (typ == OIVAE_GEN_MLP) ? p : sdact;   p += (typ == OIVAE_GEN_MLP) ? R * H : 0;
+  float* sgmu = p; p += R * DC;
+  float* sres = p; p += R * DC;
+
+  // ---- group weights -> LDS (once) ----
+  const float* Wsg = a.Ws + (int64_t)g * K * H;
+  for (int i = tid; i < K * H; i += 256) sWs[(i / H) * HP + (i % H)] = Wsg[i];
+  if (typ == OIVAE_GEN_MLP) {
+    const float* W1g = a.W1 + (int64_t)g * M * H;
+    for (int i = tid; i < M * H; i += 256) sW1[(i / H) * HP + (i % H)] = W1g[i];
+    for (int i = tid; i < M; i += 256) sb1[i] = a.b1[(int64_t)g * M + i];
+  }
+  // destinations for this chunk
+  const int64_t cs = a.chunk_stride * chunk;
+  float* gW2 = a.gW2 + cs + (int64_t)off * Hin;
+  float* gb2 = a.gb2 + cs + off;
+  float* gls = a.gls + cs + off;
+  float* gWs = a.gWs + cs + (int64_t)g * K * H;
+  float* gW1 = (typ == OIVAE_GEN_MLP) ? a.gW1 + cs + (int64_t)g * M * H : nullptr;
+  float* gb1 = (typ == OIVAE_GEN_MLP) ? a.gb1 + cs + (int64_t)g * M : nullptr;
+  const float* W2g = a.W2 + (int64_t)off * Hin;
+
+  double ll_acc = 0.0;
+  const int64_t ntiles = (a.N + R - 1) / R;
+  for (int64_t tile = chunk; tile < ntiles; tile += nchunks) {
+    const int64_t n0 = tile * R;
+    __syncthreads();
+    // A1: z tile
+    for (int i = tid; i < R * K; i += 256) {
+      const int64_t n = n0 + i / K;
+      sz[i] = (n < a.N) ? a.z[n * K + (i % K)] : 0.f;
+    }
+    __syncthreads();
+    // A2: h = z Ws[g]
+    for (int i = tid; i < R * H; i += 256) {
+      const int r = i / H, j = i - r * H;
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) acc = fmaf(sz[r * K + k], sWs[k * HP + j], acc);
+      sh[i] = acc;
+    }
+    __syncthreads();
+    // A3: activation feeding the last linear layer
+    if (typ == OIVAE_GEN_MLP) {
+      for (int i = tid; i < R * M; i += 256) {
+        const int r = i / M, m = i - r * M;
+        float acc = sb1[m];
+        for (int j = 0; j < H; ++j) acc = fmaf(sh[r * H + j], sW1[m * HP + j], acc);
+        sact[i] = tanhf(acc);
+      }
+    } else if (typ == OIVAE_GEN_TANH_LINEAR) {
+      for (int i = tid; i < R * H; i += 256) sact[i] = tanhf(sh[i]);
+    }
+    for (int i = tid; i < R * Hin; i += 256) sdact[i] = 0.f;
+    __syncthreads();
+    // ---- loop over output-column chunks of this group ----
+    float ll_tile = 0.f;
+    for (int dc0 = 0; dc0 < Dg; dc0 += DC) {
+      const int dn = min(DC, Dg - dc0);
+      // stage this chunk of the last layer
+      for (int i = tid; i < dn * Hin; i += 256) sW2[(i / Hin) * HinP + (i % Hin)] = W2g[(int64_t)dc0 * Hin + i];
+      for (int i = tid; i < dn; i += 256) {
+        const float lsv = a.ls[off + dc0 + i];
+        const float e = expf(lsv);
+        const float sg = e + a.sig_off;
+        sb2[i] = a.b2[off + dc0 + i];
+        sSig[i] = sg;
+        sLogSig[i] = logf(sg);
+        sCoef[i] = e * a.inv / sg;   // d loss / d log_sigma = sum_n (1 - ((x-mu)/sigma)^2) * e*inv/sigma
+      }
+      __syncthreads();
+      // B1: mu, residual, log-likelihood, dL/dmu
+      for (int i = tid; i < R * dn; i += 256) {
+        const int r = i / dn, dd = i - r * dn;
+        const int64_t n = n0 + r;
+        float gm = 0.f, res = 0.f;
+        if (n < a.N) {
+          float mu = sb2[dd];
+          for (int j = 0; j < Hin; ++j) mu = fmaf(sact[r * Hin + j], sW2[dd * HinP + j], mu);
+          const float x = a.X[(n % a.B) * (int64_t)a.D + off + dc0 + dd];
+          const float sg = sSig[dd];
+          const float q = (x - mu) / sg;
+          ll_tile += -0.5f * kLog2Pi - sLogSig[dd] - 0.5f * q * q;
+          gm = -(q / sg) * a.inv;
+          res = 1.f - q * q;
+        }
+        sgmu[r * DC + dd] = gm;
+        sres[r * DC + dd] = res;
+      }
+      __syncthreads();
+      // B3: dact += gmu W2   (rows x Hin)
+      for (int i = tid; i < R * Hin; i += 256) {
+        const int r = i / Hin, j = i - r * Hin;
+        float acc = sdact[i];
+        for (int dd = 0; dd < dn; ++dd) acc = fmaf(sgmu[r * DC + dd], sW2[dd * HinP + j], acc);
+        sdact[i] = acc;
+      }
+      // B4: last-layer weight grads for this chunk (fixed owner thread per element)
+      for (int i = tid; i < dn * Hin; i += 256) {
+        const int dd = i / Hin, j = i - dd * Hin;
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc = fmaf(sgmu[r * DC + dd], sact[r * Hin + j], acc);
+        gW2[(int64_t)(dc0 + dd) * Hin + j] += acc;
+      }
+      for (int i = tid; i < dn; i += 256) {
+        float accb = 0.f, accs = 0.f;
+        for (int r = 0; r < R; ++r) { accb += sgmu[r * DC + i]; accs += sres[r * DC + i]; }
+        gb2[dc0 + i] += accb;
+        gls[dc0 + i] += accs * sCoef[i];
+      }
+      __syncthreads();
+    }
+    ll_acc += (double)ll_tile;
+    // C1: back through the activation / hidden layer
+    if (typ == OIVAE_GEN_MLP) {
+      for (int i = tid; i < R * M; i += 256) { const float t = sact[i]; sdact[i] = sdact[i] * (1.f - t * t); }
+      __syncthreads();
+      for (int i = tid; i < R * H; i += 256) {
+        const int r = i / H, j = i - r * H;
+        float acc = 0.f;
+        for (int m = 0; m < M; ++m) acc = fmaf(sdact[r * M + m], sW1[m * HP + j], acc);
+        sdh[i] = acc;
+      }
+      // C2: hidden-layer weight grads
+      for (int i = tid; i < M * H; i += 256) {
+        const int m = i / H, j = i - m * H;
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc = fmaf(sdact[r * M + m], sh[r * H + j], acc);
+        gW1[i] += acc;
+      }
+      for (int i = tid; i < M; i += 256) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += sdact[r * M + i];
+        gb1[i] += acc;
+      }
+    } else if (typ == OIVAE_GEN_TANH_LINEAR) {
+      for (int i = tid; i < R * H; i += 256) { const float t = sact[i]; sdact[i] = sdact[i] * (1.f - t * t); }
+    }
+    __syncthreads();
+    // C3: dWs[g] += z^T dh
+    for (int i = tid; i < K * H; i += 256) {
+      const int k = i / H, j = i - k * H;
+      float acc = 0.f;
+      for (int r = 0; r < R; ++r) acc = fmaf(sz[r * K + k], sdh[r * H + j], acc);
+      gWs[i] += acc;
+    }
+    // C4: dz += dh Ws[g]^T   (summed over groups: float atomics)
+    for (int i = tid; i < R * K; i += 256) {
+      const int r = i / K, k = i - r * K;
+      const int64_t n = n0 + r;
+      if (n < a.N) {
+        float acc = 0.f;
+        for (int j = 0; j < H; ++j) acc = fmaf(sdh[r * H + j], sWs[k * HP + j], acc);
+        atomicAdd(a.dz + n * K + k, acc);
+      }
+    }
+  }
+  const double tot = block_sum_double(ll_acc, sred);
+  if (tid == 0) a.ll_part[(int64_t)chunk * gridDim.x + g] = tot;
+}
+
+// grads[i] = sum_c slab[c][i], c in index order
+__global__ __launch_bounds__(256) void slab_reduce(const float* __restrict__ slab, int64_t P, int chunks,
+                                                   float* __restrict__ dst, int64_t seg_off, int64_t seg_n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < seg_n; i += stride) {
+    float acc = 0.f;
+    for (int c = 0; c < chunks; ++c) acc += slab[(int64_t)c * P + seg_off + i];
+    dst[i] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------
+// encoder backward (lib/oivae.py:75, encoder half)
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void enc_bwd_pre(int64_t B, int K, int S, const float* __restrict__ dz,
+                                                   const float* __restrict__ eps, float c,
+                                                   const float* __restrict__ prior_mu,
+                                                   const float* __restrict__ prior_sigma, int prior_stride,
+                                                   const float* __restrict__ mu_q,
+                                                   const float* __restrict__ sig_q,
+                                                   const float* __restrict__ ea, float* __restrict__ dpre) {
+  const int64_t total = B * K;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float invB = 1.0f / (float)B;
+  for (; i < total; i += stride) {
+    const int64_t b = i / K;
+    const int k = (int)(i - b * K);
+    float sdz = 0.f, sdze = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const int64_t n = (int64_t)s * B + b;
+      const float d = dz[n * K + k];
+      sdz += d;
+      sdze = fmaf(d, eps[n * K + k], sdze);
+    }
+    const float mp = prior_mu[b * prior_stride + k], sp = prior_sigma[b * prior_stride + k];
+    const float sq = sig_q[i];
+    const float dmu = sdz + ((mu_q[i] - mp) / (sp * sp)) * invB;
+    const float dsig = sdze + (sq / (sp * sp) - 1.0f / sq) * invB;
+    dpre[b * 2 * K + k] = dmu;
+    dpre[b * 2 * K + K + k] = dsig * c * ea[i];
+  }
+}
+
+// one block per column j of dpre [B, J]: bias gradients
+__global__ __launch_bounds__(256) void enc_bwd_bias(const float* __restrict__ dpre, int64_t B, int K,
+                                                    float* __restrict__ dbmu, float* __restrict__ dbsig) {
+  __shared__ double sred[256];
+  const int j = blockIdx.x, J = 2 * K;
+  double acc = 0.0;
+  for (int64_t b = threadIdx.x; b < B; b += 256) acc += (double)dpre[b * J + j];
+  const double tot = block_sum_double(acc, sred);
+  if (threadIdx.x == 0) {
+    if (j < K) dbmu[j] = (float)tot; else dbsig[j - K] = (float)tot;
+  }
+}
+
+// dW[j][d] = sum_b dpre[b][j] X[b][d]; block = 32 j x 64 d, loops over all b in order
+__global__ __launch_bounds__(256) void enc_bwd_wgrad_generic(const float* __restrict__ X,
+                                                             const float* __restrict__ dpre, int64_t B,
+                                                             int D, int K, float* __restrict__ dWmu,
+                                                             float* __restrict__ dWsig) {
+  __shared__ float sX[64][65];
+  __shared__ float sP[64][33];
+  const int J = 2 * K;
+  const int tid = threadIdx.x;
+  const int dd = tid & 63, jj = tid >> 6;
+  const int d0 = blockIdx.x * 64, j0 = blockIdx.y * 32;
+  float acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+  for (int64_t bb0 = 0; bb0 < B; bb0 += 64) {
+    __syncthreads();
+    for (int i = tid; i < 64 * 64; i += 256) {
+      const int rr = i >> 6, cc = i & 63;
+      const int64_t b = bb0 + rr;
+      sX[rr][cc] = (b < B && d0 + cc < D) ? X[b * D + d0 + cc] : 0.f;
+    }
+    for (int i = tid; i < 64 * 32; i += 256) {
+      const int rr = i >> 5, cc = i & 31;
+      const int64_t b = bb0 + rr;
+      sP[rr][cc] = (b < B && j0 + cc < J) ? dpre[b * J + j0 + cc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int rr = 0; rr < 64; ++rr) {
+      const float xv = sX[rr][dd];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = fmaf(sP[rr][jj + 4 * q], xv, acc[q]);
+    }
+  }
+  if (d0 + dd < D) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = j0 + jj + 4 * q;
+      if (j < K) dWmu[(int64_t)j * D + d0 + dd] = acc[q];
+      else if (j < J) dWsig[(int64_t)(j - K) * D + d0 + dd] = acc[q];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------
+static int64_t dec_lds_floats(const oivae_shape_t& s, int R, int DC) {
+  const int Hin = (s.gen_type == OIVAE_GEN_MLP) ? s.M : s.H;
+  const int HP = s.H | 1, HinP = Hin | 1;
+  int64_t n = (int64_t)s.K * HP;
+  if (s.gen_type == OIVAE_GEN_MLP) n += (int64_t)s.M * HP + s.M;
+  n += (int64_t)DC * HinP + 4 * DC;
+  n += (int64_t)R * s.K + (int64_t)R * s.H;
+  if (s.gen_type != OIVAE_GEN_LINEAR) n += (int64_t)R * Hin;
+  n += (int64_t)R * Hin;
+  if (s.gen_type == OIVAE_GEN_MLP) n += (int64_t)R * s.H;
+  n += 2 * (int64_t)R * DC;
+  return n;
+}
+
+bool mfma_decoder_applies(const oivae_shape_t& s);  // mfma_decoder.hip
+
+DecPlan plan_decoder(const oivae_shape_t& s, int64_t N) {
+  DecPlan pl;
+  pl.mfma = mfma_decoder_applies(s);
+  pl.DC = s.max_group_dim < 64 ? s.max_group_dim : 64;
+  pl.R = 0;
+  pl.lds_bytes = 0;
+  const int cand[3] = {64, 32, 16};
+  for (int i = 0; i < 3; ++i) {
+    const int64_t bytes = dec_lds_floats(s, cand[i], pl.DC) * 4;
+    if (bytes <= 150 * 1024) { pl.R = cand[i]; pl.lds_bytes = bytes; break; }
+  }
+  const int64_t R = pl.R ? pl.R : 16;
+  const int64_t tiles = (N + R - 1) / R;
+  int64_t c = (2048 + s.G - 1) / s.G;
+  if (c > tiles) c = tiles;
+  if (c < 1) c = 1;
+  if ((int64_t)s.G * c > kMaxPartials) c = kMaxPartials / s.G > 0 ? kMaxPartials / s.G : 1;
+  pl.chunks = (int32_t)c;
+  if (pl.mfma) pl.chunks = 1;
+  return pl;
+}
+
+int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, const oivae_tensors_t* grads,
+                        const float* X, int64_t B, int32_t S, const float* z, float gen_sig_off, float* dz,
+                        Workspace& w, hipStream_t st);  // mfma_decoder.hip
+
+}  // namespace oivae
+
+using namespace oivae;
+
+extern "C" int oivae_encoder_fwd_f32(const oivae_shape_t* shape, const oivae_tensors_t* params,
+                                     const float* X, int64_t B, int32_t S, const float* eps, float c,
+                                     float sig_off, const float* prior_mu, const float* prior_sigma,
+                                     int32_t prior_rows, float* mu_q, float* sig_q, float* ea, float* z,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+  if (int rc = check_shape(shape)) return rc;
+  if (!params || !X || !eps || !prior_mu || !prior_sigma || !mu_q || !sig_q || !ea || !z || !workspace)
+    return fail(OIVAE_E_ARG, "oivae_encoder_fwd_f32: null pointer");
+  if (B < 1 || S < 1) return fail(OIVAE_E_ARG, "oivae_encoder_fwd_f32: B and S must be >= 1");
+  if (prior_rows != 1 && prior_rows != B)
+    return fail(OIVAE_E_ARG, "oivae_encoder_fwd_f32: prior_rows must be 1 or B (got %d, B=%lld)", prior_rows, (long long)B);
+  Workspace w;
+  if (int rc = carve_workspace(*shape, B, S, workspace, workspace_bytes, &w)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t blocks = (B + kEncRows - 1) / kEncRows;
+  if (blocks > w.n_kl) return fail(OIVAE_E_SHAPE, "oivae_encoder_fwd_f32: batch %lld too large for the generic encoder", (long long)B);
+  OIVAE_HIP_CHECK(hipMemsetAsync(w.kl_part, 0, sizeof(double) * w.n_kl, st));
+  const size_t lds = sizeof(float) * ((size_t)kEncRows * (kEncDC + 1) + (size_t)kEncRows * 2 * shape->K);
+  hipLaunchKernelGGL(enc_fwd_generic, dim3((unsigned)blocks), dim3(256), lds, st, X, B, shape->D, shape->K,
+                     params->enc_Wmu, params->enc_bmu, params->enc_Wsig, params->enc_bsig, S, eps, c, sig_off,
+                     prior_mu, prior_sigma, prior_rows == 1 ? 0 : shape->K, mu_q, sig_q, ea, z, w.kl_part);
+  OIVAE_LAUNCH_CHECK();
+  return OIVAE_OK;
+}
+
+extern "C" int oivae_decoder_fwd_bwd_f32(const oivae_shape_t* shape, const oivae_tensors_t* params,
+                                         const oivae_tensors_t* grads, const float* X, int64_t B, int32_t S,
+                                         const float* z, float gen_sig_off, float* dz, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
+  if (int rc = check_shape(shape)) return rc;
+  if (!params || !grads || !X || !z || !dz || !workspace)
+    return fail(OIVAE_E_ARG, "oivae_decoder_fwd_bwd_f32: null pointer");
+  if (B < 1 || S < 1) return fail(OIVAE_E_ARG, "oivae_decoder_fwd_bwd_f32: B and S must be >= 1");
+  const oivae_shape_t& s = *shape;
+  Workspace w;
+  if (int rc = carve_workspace(s, B, S, workspace, workspace_bytes, &w)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t N = B * (int64_t)S;
+  const DecPlan pl = plan_decoder(s, N);
+  OIVAE_HIP_CHECK(hipMemsetAsync(w.ll_part, 0, sizeof(double) * w.n_ll, st));
+  OIVAE_HIP_CHECK(hipMemsetAsync(dz, 0, sizeof(float) * N * s.K, st));
+  if (pl.mfma) return launch_decoder_mfma(s, params, grads, X, B, S, z, gen_sig_off, dz, w, st);
+  if (pl.R == 0)
+    return fail(OIVAE_E_SHAPE, "oivae_decoder_fwd_bwd_f32: group weights do not fit LDS (K=%d H=%d M=%d)", s.K, s.H, s.M);
+  const DecLayout L = dec_layout(s);
+  const bool mlp = s.gen_type == OIVAE_GEN_MLP;
+  DecArgs a;
+  a.D = s.D; a.K = s.K; a.G = s.G; a.H = s.H; a.M = s.M; a.Hin = mlp ? s.M : s.H; a.gen_type = s.gen_type;
+  a.group_off = s.group_off;
+  a.W1 = params->gen_W1; a.b1 = params->gen_b1; a.W2 = params->gen_W2; a.b2 = params->gen_b2;
+  a.ls = params->log_sigma; a.Ws = params->Ws;
+  if (pl.chunks > 1) {
+    OIVAE_HIP_CHECK(hipMemsetAsync(w.slab, 0, sizeof(float) * L.total * pl.chunks, st));
+    a.gW1 = w.slab + L.oW1; a.gb1 = w.slab + L.ob1; a.gW2 = w.slab + L.oW2; a.gb2 = w.slab + L.ob2;
+    a.gls = w.slab + L.oLs; a.gWs = w.slab + L.oWs;
+    a.chunk_stride = L.total;
+  } else {
+    if (mlp) {
+      OIVAE_HIP_CHECK(hipMemsetAsync(grads->gen_W1, 0, sizeof(float) * (L.ob1 - L.oW1), st));
+      OIVAE_HIP_CHECK(hipMemsetAsync(grads->gen_b1, 0, sizeof(float) * (L.oW2 - L.ob1), st));
+    }
+    OIVAE_HIP_CHECK(hipMemsetAsync(grads->gen_W2, 0, sizeof(float) * (L.ob2 - L.oW2), st));
+    OIVAE_HIP_CHECK(hipMemsetAsync(grads->gen_b2, 0, sizeof(float) * (L.oLs - L.ob2), st));
+    OIVAE_HIP_CHECK(hipMemsetAsync(grads->log_sigma, 0, sizeof(float) * (L.oWs - L.oLs), st));
+    OIVAE_HIP_CHECK(hipMemsetAsync(grads->Ws, 0, sizeof(float) * (L.total - L.oWs), st));
+    a.gW1 = grads->gen_W1; a.gb1 = grads->gen_b1; a.gW2 = grads->gen_W2; a.gb2 = grads->gen_b2;
+    a.gls = grads->log_sigma; a.gWs = grads->Ws;
+    a.chunk_stride = 0;
+  }
+  a.X = X; a.z = z; a.dz = dz; a.B = B; a.N = N;
+  a.inv = 1.0f / ((float)S * (float)B);
+  a.sig_off = gen_sig_off;
+  a.DC = pl.DC;
+  a.ll_part = w.ll_part;
+  const dim3 grid((unsigned)s.G, (unsigned)pl.chunks);
+#define OIVAE_DEC_LAUNCH(RR)                                                                             \
+  {                                                                                                      \
+    OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_generic<RR>),                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes)); \
+    hipLaunchKernelGGL((dec_generic<RR>), grid, dim3(256), (size_t)pl.lds_bytes, st, a);                  \
+  }
+  if (pl.R == 64) OIVAE_DEC_LAUNCH(64)
+  else if (pl.R == 32) OIVAE_DEC_LAUNCH(32)
+  else OIVAE_DEC_LAUNCH(16)
+#undef OIVAE_DEC_LAUNCH
+  OIVAE_LAUNCH_CHECK();
+  if (pl.chunks > 1) {
+    struct Seg { float* dst; int64_t off, n; };
+    const Seg segs[6] = {{grads->gen_W1, L.oW1, L.ob1 - L.oW1}, {grads->gen_b1, L.ob1, L.oW2 - L.ob1},
+                         {grads->gen_W2, L.oW2, L.ob2 - L.oW2}, {grads->gen_b2, L.ob2, L.oLs - L.ob2},
+                         {grads->log_sigma, L.oLs, L.oWs - L.oLs}, {grads->Ws, L.oWs, L.total - L.oWs}};
+    for (int q = 0; q < 6; ++q) {
+      if (segs[q].n == 0) continue;
+      if (!segs[q].dst) return fail(OIVAE_E_ARG, "oivae_decoder_fwd_bwd_f32: null grad tensor %d", q);
+      int64_t blocks = (segs[q].n + 255) / 256;
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(slab_reduce, dim3((unsigned)blocks), dim3(256), 0, st, w.slab, L.total, pl.chunks,
+                         segs[q].dst, segs[q].off, segs[q].n);
+      OIVAE_LAUNCH_CHECK();
+    }
+  }
+  return OIVAE_OK;
+}
+
+extern "C" int oivae_encoder_bwd_f32(const oivae_shape_t* shape, const oivae_tensors_t* grads, const float* X,
+                                     int64_t B, int32_t S, const float* eps, float c, const float* prior_mu,
+                                     const float* prior_sigma, int32_t prior_rows, const float* mu_q,
+                                     const float* sig_q, const float* ea, const float* dz, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+  if (int rc = check_shape(shape)) return rc;
+  if (!grads || !X || !eps || !prior_mu || !prior_sigma || !mu_q || !sig_q || !ea || !dz || !workspace)
+    return fail(OIVAE_E_ARG, "oivae_encoder_bwd_f32: null pointer");
+  if (B < 1 || S < 1) return fail(OIVAE_E_ARG, "oivae_encoder_bwd_f32: B and S must be >= 1");
+  if (prior_rows != 1 && prior_rows != B) return fail(OIVAE_E_ARG, "oivae_encoder_bwd_f32: prior_rows must be 1 or B");
+  const oivae_shape_t& s = *shape;
+  Workspace w;
+  if (int rc = carve_workspace(s, B, S, workspace, workspace_bytes, &w)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t blocks = (B * s.K + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(enc_bwd_pre, dim3((unsigned)blocks), dim3(256), 0, st, B, s.K, S, dz, eps, c, prior_mu,
+                     prior_sigma, prior_rows == 1 ? 0 : s.K, mu_q, sig_q, ea, w.dpre);
+  OIVAE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(enc_bwd_bias, dim3((unsigned)(2 * s.K)), dim3(256), 0, st, w.dpre, B, s.K, grads->enc_bmu,
+                     grads->enc_bsig);
+  OIVAE_LAUNCH_CHECK();
+  const dim3 grid((unsigned)((s.D + 63) / 64), (unsigned)((2 * s.K + 31) / 32));
+  hipLaunchKernelGGL(enc_bwd_wgrad_generic, grid, dim3(256), 0, st, X, w.dpre, B, s.D, s.K, grads->enc_Wmu,
+                     grads->enc_Wsig);
+  OIVAE_LAUNCH_CHECK();
+  return OIVAE_OK;
+}

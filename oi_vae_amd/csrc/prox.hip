@@ -1,0 +1,255 @@
+// Group-lasso proximal step (block soft-threshold of every row of Ws) for gfx950.
+//
+// Replaces BayesianGroupLassoGenerator.proximal_step
+// (/root/reference/lib/models.py:106-111), optionally fused with the plain SGD
+// update of Ws that precedes it (/root/reference/lib/oivae.py:76-79).
+//
+// HBM-bound: one read and one write of Ws (8 B/element; 12 with the fused SGD,
+// which also reads dWs) plus one mask byte per row.  The arithmetic is pinned
+// bit for bit to the reference's CPU path -- see oracle/prox_oracle.c for the
+// derivation of each rule:
+//   * w*w and every partial sum rounded to fp32 (this TU is built with
+//     -ffp-contract=off), summed in the order of torch 2.10's CPU sum kernel;
+//   * the square root is MKL-VML's vmsSqrt(HA): rsqrt14 table lookup plus one
+//     fused Newton step, not the correctly rounded root;
+//   * divide and multiply correctly rounded, two roundings per element.
+#include "common.h"
+
+namespace oivae {
+
+__device__ __forceinline__ float mkl_sqrtf_dev(float x, const uint16_t* __restrict__ tab) {
+  if (!(x > 0.0f) || x == __builtin_inff()) return x;  // 0, NaN, +inf pass through (x is a sum of squares)
+  float back = 1.0f;
+  if (x < 0x1p-100f) { x *= 0x1p64f; back = 0x1p-32f; }
+  const uint32_t u = __float_as_uint(x);
+  const int e = (int)(u >> 23) - 127;
+  const uint32_t m = u & 0x7fffffu;
+  const int par = e & 1;
+  const int half = (e - par) >> 1;
+  float y;
+  if (par == 0 && m == 0) {
+    y = __uint_as_float((uint32_t)(127 - half) << 23);
+  } else {
+    const uint32_t frac = tab[par * 32768 + (m >> 8)];
+    y = __uint_as_float(((uint32_t)(126 - half) << 23) | (frac << 7));
+  }
+  const float s = x * y;
+  const float h = 0.5f * y;
+  const float d = __builtin_fmaf(-s, s, x);
+  return __builtin_fmaf(d, h, s) * back;
+}
+
+__device__ __forceinline__ void prox_scales(float n, float t, float& den, float& sc) {
+  den = (n < 1e-16f) ? 1e-16f : n;  // clamp(n, min=1e-16); NaN passes through
+  sc = n - t;
+  if (sc < 0.0f) sc = 0.0f;         // clamp(n - t, min=0); NaN passes through
+}
+
+// ---- path A: any H, one thread per row, scalar emulation of the sum order ----
+template <bool SGD>
+__global__ __launch_bounds__(256) void prox_rows_scalar(float* __restrict__ Ws,
+                                                        const float* __restrict__ dWs,
+                                                        int64_t rows, int H, float neg_lr, float t,
+                                                        int do_prox,
+                                                        uint8_t* __restrict__ mask,
+                                                        float* __restrict__ norms,
+                                                        const uint16_t* __restrict__ tab) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float* w = Ws + r * H;
+  const float* g = SGD ? dWs + r * H : nullptr;
+  auto ld = [&](int i) -> float {
+    float v = w[i];
+    if (SGD) v = __builtin_fmaf(neg_lr, g[i], v);
+    return v;
+  };
+  float acc;
+  if (H < 8) {
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    const int nq = H / 4;
+    for (int i = 0; i < nq; ++i) {
+      float a0 = ld(4 * i), a1 = ld(4 * i + 1), a2 = ld(4 * i + 2), a3 = ld(4 * i + 3);
+      p0 = p0 + a0 * a0; p1 = p1 + a1 * a1; p2 = p2 + a2 * a2; p3 = p3 + a3 * a3;
+    }
+    for (int i = nq * 4; i < H; ++i) { float a = ld(i); p0 = p0 + a * a; }
+    p0 = p0 + p1; p0 = p0 + p2; p0 = p0 + p3;
+    acc = p0;
+  } else {
+    float P[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int l = 0; l < 8; ++l) P[k][l] = 0.f;
+    const int V = H / 8, nq = V / 4;
+    for (int i = 0; i < nq; ++i) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) { float a = ld((4 * i + k) * 8 + l); P[k][l] = P[k][l] + a * a; }
+    }
+    for (int i = nq * 4; i < V; ++i)
+#pragma unroll
+      for (int l = 0; l < 8; ++l) { float a = ld(i * 8 + l); P[0][l] = P[0][l] + a * a; }
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+#pragma unroll
+      for (int l = 0; l < 8; ++l) P[0][l] = P[0][l] + P[k][l];
+    acc = 0.f;
+    for (int i = V * 8; i < H; ++i) { float a = ld(i); acc = acc + a * a; }
+#pragma unroll
+    for (int l = 0; l < 8; ++l) acc = acc + P[0][l];
+  }
+  const float n = mkl_sqrtf_dev(acc, tab);
+  float den, sc;
+  prox_scales(n, t, den, sc);
+  bool allzero = true;
+  for (int i = 0; i < H; ++i) {
+    float v = ld(i);
+    if (do_prox) { v = v / den; v = v * sc; }
+    w[i] = v;
+    allzero = allzero && (v == 0.0f);
+  }
+  if (mask) mask[r] = allzero ? 1 : 0;
+  if (norms) norms[r] = n;
+}
+
+// ---- path B: H = 8*V, two threads per row, 16-byte accesses, row in registers ----
+// Thread `hh` of a row owns lanes 4hh..4hh+3 of every 8-float vector, which is
+// exactly what one lane group of the CPU kernel's vector accumulators sees.
+template <int V, bool SGD>
+__global__ __launch_bounds__(256) void prox_rows_vec(float* __restrict__ Ws,
+                                                     const float* __restrict__ dWs,
+                                                     int64_t rows, float neg_lr, float t, int do_prox,
+                                                     uint8_t* __restrict__ mask,
+                                                     float* __restrict__ norms,
+                                                     const uint16_t* __restrict__ tab) {
+  constexpr int H = 8 * V;
+  const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = gt >> 1;
+  const int hh = (int)(gt & 1);
+  const bool live = r < rows;
+  float4 v[V];
+  if (live) {
+    const float4* wp = reinterpret_cast<const float4*>(Ws + r * H) + hh;
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = wp[2 * i];
+    if (SGD) {
+      const float4* gp = reinterpret_cast<const float4*>(dWs + r * H) + hh;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const float4 g = gp[2 * i];
+        v[i].x = __builtin_fmaf(neg_lr, g.x, v[i].x);
+        v[i].y = __builtin_fmaf(neg_lr, g.y, v[i].y);
+        v[i].z = __builtin_fmaf(neg_lr, g.z, v[i].z);
+        v[i].w = __builtin_fmaf(neg_lr, g.w, v[i].w);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 P[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) P[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int NQ = V / 4;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int k = (i < 4 * NQ) ? (i & 3) : 0;
+    P[k].x = P[k].x + v[i].x * v[i].x;
+    P[k].y = P[k].y + v[i].y * v[i].y;
+    P[k].z = P[k].z + v[i].z * v[i].z;
+    P[k].w = P[k].w + v[i].w * v[i].w;
+  }
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    P[0].x = P[0].x + P[k].x; P[0].y = P[0].y + P[k].y;
+    P[0].z = P[0].z + P[k].z; P[0].w = P[0].w + P[k].w;
+  }
+  // lanes 0..7 left to right: lanes 0-3 live in the even thread, 4-7 in the odd one
+  const float o0 = __shfl_xor(P[0].x, 1), o1 = __shfl_xor(P[0].y, 1);
+  const float o2 = __shfl_xor(P[0].z, 1), o3 = __shfl_xor(P[0].w, 1);
+  float l0, l1, l2, l3, l4, l5, l6, l7;
+  if (hh == 0) { l0 = P[0].x; l1 = P[0].y; l2 = P[0].z; l3 = P[0].w; l4 = o0; l5 = o1; l6 = o2; l7 = o3; }
+  else         { l0 = o0; l1 = o1; l2 = o2; l3 = o3; l4 = P[0].x; l5 = P[0].y; l6 = P[0].z; l7 = P[0].w; }
+  float acc = 0.f;
+  acc = acc + l0; acc = acc + l1; acc = acc + l2; acc = acc + l3;
+  acc = acc + l4; acc = acc + l5; acc = acc + l6; acc = acc + l7;
+  const float n = mkl_sqrtf_dev(acc, tab);
+  float den, sc;
+  prox_scales(n, t, den, sc);
+  bool allzero = true;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    if (do_prox) {
+      v[i].x = v[i].x / den; v[i].x = v[i].x * sc;
+      v[i].y = v[i].y / den; v[i].y = v[i].y * sc;
+      v[i].z = v[i].z / den; v[i].z = v[i].z * sc;
+      v[i].w = v[i].w / den; v[i].w = v[i].w * sc;
+    }
+    allzero = allzero && (v[i].x == 0.f) && (v[i].y == 0.f) && (v[i].z == 0.f) && (v[i].w == 0.f);
+  }
+  const int other = __shfl_xor((int)allzero, 1);
+  if (live) {
+    float4* wp = reinterpret_cast<float4*>(Ws + r * H) + hh;
+#pragma unroll
+    for (int i = 0; i < V; ++i) wp[2 * i] = v[i];
+    if (hh == 0) {
+      if (mask) mask[r] = (allzero && other) ? 1 : 0;
+      if (norms) norms[r] = n;
+    }
+  }
+}
+
+template <bool SGD>
+static int launch_prox(float* Ws, const float* dWs, int64_t rows, int H, float lr, float t,
+                       int do_prox, uint8_t* mask, float* norms, hipStream_t st) {
+  const uint16_t* tab = rsqrt14_table_device();
+  if (!tab) return fail(OIVAE_E_NOINIT, "oivae_init has not been called on this device");
+  if (rows == 0) return OIVAE_OK;
+  const float neg_lr = -lr;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(Ws) & 15) == 0) &&
+                       (!SGD || (reinterpret_cast<uintptr_t>(dWs) & 15) == 0);
+#define OIVAE_PROX_VEC(VV)                                                                      \
+  {                                                                                              \
+    const int64_t threads = rows * 2;                                                            \
+    const unsigned blocks = (unsigned)((threads + 255) / 256);                                   \
+    hipLaunchKernelGGL((prox_rows_vec<VV, SGD>), dim3(blocks), dim3(256), 0, st, Ws, dWs, rows,  \
+                       neg_lr, t, do_prox, mask, norms, tab);                                    \
+  }
+  if (aligned && H == 8) OIVAE_PROX_VEC(1)
+  else if (aligned && H == 16) OIVAE_PROX_VEC(2)
+  else if (aligned && H == 32) OIVAE_PROX_VEC(4)
+  else if (aligned && H == 64) OIVAE_PROX_VEC(8)
+  else if (aligned && H == 128) OIVAE_PROX_VEC(16)
+  else {
+    const unsigned blocks = (unsigned)((rows + 255) / 256);
+    hipLaunchKernelGGL((prox_rows_scalar<SGD>), dim3(blocks), dim3(256), 0, st, Ws, dWs, rows, H,
+                       neg_lr, t, do_prox, mask, norms, tab);
+  }
+#undef OIVAE_PROX_VEC
+  OIVAE_LAUNCH_CHECK();
+  return OIVAE_OK;
+}
+
+}  // namespace oivae
+
+using namespace oivae;
+
+extern "C" int oivae_prox_f32(float* Ws, int64_t rows, int32_t H, float t, uint8_t* zero_mask,
+                              float* row_norms, void* stream) {
+  if (!Ws || rows < 0) return fail(OIVAE_E_ARG, "oivae_prox_f32: null Ws or negative rows");
+  if (H < 1 || H >= 512)
+    return fail(OIVAE_E_SHAPE, "oivae_prox_f32: H=%d outside [1,512) (the reference's row-sum order is pinned only there)", H);
+  if (rows * 2 / 256 > 0x7fffffffLL) return fail(OIVAE_E_SHAPE, "oivae_prox_f32: too many rows");
+  return launch_prox<false>(Ws, nullptr, rows, H, 0.f, t, 1, zero_mask, row_norms, (hipStream_t)stream);
+}
+
+extern "C" int oivae_sgd_prox_f32(float* Ws, const float* dWs, int64_t rows, int32_t H, float lr,
+                                  float t, int32_t do_prox, uint8_t* zero_mask, float* row_norms,
+                                  void* stream) {
+  if (!Ws || !dWs || rows < 0) return fail(OIVAE_E_ARG, "oivae_sgd_prox_f32: null pointer or negative rows");
+  if (H < 1 || H >= 512)
+    return fail(OIVAE_E_SHAPE, "oivae_sgd_prox_f32: H=%d outside [1,512)", H);
+  if (rows * 2 / 256 > 0x7fffffffLL) return fail(OIVAE_E_SHAPE, "oivae_sgd_prox_f32: too many rows");
+  return launch_prox<true>(Ws, dWs, rows, H, lr, t, do_prox ? 1 : 0, zero_mask, row_norms, (hipStream_t)stream);
+}
