@@ -82,5 +82,7 @@ DecPlan plan_decoder(const oivae_shape_t& s, int64_t N);
 int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, int64_t bytes,
                     Workspace* out);
 int check_shape(const oivae_shape_t* s);
+void launch_slab_reduce(const float* slab, int64_t P, int chunks, float* dst, int64_t seg_off, int64_t seg_n,
+                        unsigned blocks, hipStream_t st);
 
 }  // namespace oivae

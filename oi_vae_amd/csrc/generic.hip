@@ -324,10 +324,19 @@ __global__ __launch_bounds__(256) void slab_reduce(const float* __restrict__ sla
   }
 }
 
+void launch_slab_reduce(const float* slab, int64_t P, int chunks, float* dst, int64_t seg_off, int64_t seg_n,
+                        unsigned blocks, hipStream_t st) {
+  if (seg_n == 0) return;
+  hipLaunchKernelGGL(slab_reduce, dim3(blocks), dim3(256), 0, st, slab, P, chunks, dst, seg_off, seg_n);
+}
+
 // ------------------------------------------------------------------------------
 // encoder backward (lib/oivae.py:75, encoder half)
 // ------------------------------------------------------------------------------
+// dz element (n, k) lives at dz[n*dz_sn + k*dz_sk]: [N,K] from the generic decoder,
+// [K,N] from the MFMA decoder
 __global__ __launch_bounds__(256) void enc_bwd_pre(int64_t B, int K, int S, const float* __restrict__ dz,
+                                                   int64_t dz_sn, int64_t dz_sk,
                                                    const float* __restrict__ eps, float c,
                                                    const float* __restrict__ prior_mu,
                                                    const float* __restrict__ prior_sigma, int prior_stride,
@@ -344,7 +353,7 @@ __global__ __launch_bounds__(256) void enc_bwd_pre(int64_t B, int K, int S, cons
     float sdz = 0.f, sdze = 0.f;
     for (int s = 0; s < S; ++s) {
       const int64_t n = (int64_t)s * B + b;
-      const float d = dz[n * K + k];
+      const float d = dz[n * dz_sn + k * dz_sk];
       sdz += d;
       sdze = fmaf(d, eps[n * K + k], sdze);
     }
@@ -431,7 +440,8 @@ static int64_t dec_lds_floats(const oivae_shape_t& s, int R, int DC) {
   return n;
 }
 
-bool mfma_decoder_applies(const oivae_shape_t& s);  // mfma_decoder.hip
+bool mfma_decoder_applies(const oivae_shape_t& s);          // mfma_decoder.hip
+int mfma_decoder_chunks(const oivae_shape_t& s, int64_t N);  // mfma_decoder.hip
 
 DecPlan plan_decoder(const oivae_shape_t& s, int64_t N) {
   DecPlan pl;
@@ -451,7 +461,7 @@ DecPlan plan_decoder(const oivae_shape_t& s, int64_t N) {
   if (c < 1) c = 1;
   if ((int64_t)s.G * c > kMaxPartials) c = kMaxPartials / s.G > 0 ? kMaxPartials / s.G : 1;
   pl.chunks = (int32_t)c;
-  if (pl.mfma) pl.chunks = 1;
+  if (pl.mfma) pl.chunks = mfma_decoder_chunks(s, N);
   return pl;
 }
 
@@ -583,7 +593,9 @@ extern "C" int oivae_encoder_bwd_f32(const oivae_shape_t* shape, const oivae_ten
   hipStream_t st = (hipStream_t)stream;
   int64_t blocks = (B * s.K + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(enc_bwd_pre, dim3((unsigned)blocks), dim3(256), 0, st, B, s.K, S, dz, eps, c, prior_mu,
+  const bool dz_transposed = plan_decoder(s, B * (int64_t)S).mfma;
+  const int64_t dz_sn = dz_transposed ? 1 : s.K, dz_sk = dz_transposed ? B * (int64_t)S : 1;
+  hipLaunchKernelGGL(enc_bwd_pre, dim3((unsigned)blocks), dim3(256), 0, st, B, s.K, S, dz, dz_sn, dz_sk, eps, c, prior_mu,
                      prior_sigma, prior_rows == 1 ? 0 : s.K, mu_q, sig_q, ea, w.dpre);
   OIVAE_LAUNCH_CHECK();
   hipLaunchKernelGGL(enc_bwd_bias, dim3((unsigned)(2 * s.K)), dim3(256), 0, st, w.dpre, B, s.K, grads->enc_bmu,
