@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- oi-VAE train samples/s (fwd + bwd + optimizers + prox) on MI355X.
+
+Workload (BASELINE.json configs[3], "synthetic scale-up"): G=1024 groups x 64
+dims, K=64, two-layer generators Linear(64,64)->Tanh->Linear(64,64), global
+batch 65536, S=1, synthetic X ~ U[0,1) resident in HBM, random-init weights.
+One step = encoder fwd + reparam + KL, grouped decoder fwd+bwd, encoder bwd,
+weight prior + penalty, [gradient all-reduce over RCCL when N>1], fused Adam,
+fused SGD + proximal step.  N>1: one process per GPU (torchrun), the global
+batch is sharded over ranks ("strong" scaling, as BASELINE.json states it).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+G, DG, K, H, M = 1024, 64, 64, 64, 64
+GLOBAL_BATCH = 65536
+LR, WS_LR, LAM = 1e-3, 1e-4, 1.0
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+
+
+def decoder_flops_per_row():
+  # fwd + dgrad + wgrad of the three per-group products
+  return 3 * G * (2 * K * H + 2 * H * M + 2 * M * DG)
+
+
+def encoder_flops_per_row():
+  return 2 * (4 * (G * DG) * K)
+
+
+def init_engine(device, batch_rows, seed):
+  from oi_vae_amd import Engine, ModelSpec
+  spec = ModelSpec(D=G * DG, K=K, H=H, M=M, group_dims=[DG] * G, gen_type="mlp")
+  eng = Engine(spec, device=device)
+  gen = torch.Generator(device=device).manual_seed(1234)  # same parameters on every rank
+
+  def uniform_(t, fan_in):
+    bound = 1.0 / (fan_in ** 0.5)
+    t.copy_((torch.rand(t.shape, generator=gen, device=device) * 2 - 1) * bound)
+
+  D = spec.D
+  uniform_(eng.p["enc_Wmu"], D); uniform_(eng.p["enc_bmu"], D)
+  uniform_(eng.p["enc_Wsig"], D); uniform_(eng.p["enc_bsig"], D)
+  uniform_(eng.p["gen_W1"], H); uniform_(eng.p["gen_b1"], H)
+  uniform_(eng.p["gen_W2"], M); uniform_(eng.p["gen_b2"], M)
+  eng.p["log_sigma"].fill_(float(torch.log(torch.tensor(1e-2))))
+  eng.p["Ws"].copy_(torch.randn(eng.p["Ws"].shape, generator=gen, device=device))
+  xg = torch.Generator(device=device).manual_seed(seed)
+  X = torch.rand(batch_rows, D, generator=xg, device=device)
+  return eng, X
+
+
+def cpu_baseline(batch=256):
+  """The oracle (CPU restatement with the reference's per-group loop) on the host
+  cores, same shapes at a reduced batch; reported, not a target."""
+  import numpy as np
+  from oracle import oivae_oracle as O
+  torch.set_num_threads(max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))))
+  spec = dict(D=G * DG, K=K, H=H, M=M, gen_type="mlp", group_dims=[DG] * G)
+  params = O.init_params(spec, seed=0)
+  tr = O.OracleTrainer(spec, params, lr=LR, Ws_lr=WS_LR, lam=LAM)
+  rng = np.random.default_rng(0)
+  X = rng.random((batch, spec["D"]), dtype=np.float32)
+  eps = rng.standard_normal((1, batch, K)).astype(np.float32)
+  t0 = time.perf_counter()
+  tr.step(X, eps, c=1.0, prox_step_size=WS_LR * LAM, want_grads=False)
+  dt = time.perf_counter() - t0
+  return {"value": batch / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+          "sample": "1 oracle step of the same shapes at batch %d (%.1f s)" % (batch, dt)}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=10)
+  ap.add_argument("--warmup", type=int, default=3)
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  args = ap.parse_args()
+
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit("launch with torchrun --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+  torch.cuda.set_device(local_rank)
+  device = torch.device("cuda", local_rank)
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=device)
+  from oi_vae_amd import parallel
+
+  rows = GLOBAL_BATCH // world
+  eng, X = init_engine(device, rows, seed=100 + rank)
+  egen = torch.Generator(device=device).manual_seed(7 + rank)
+  t_prox = WS_LR * LAM
+  dec_events = []
+
+  def step(timed):
+    eps = torch.randn(1, rows, K, generator=egen, device=device)
+    if timed:
+      eng.trace = dec_events
+    eng.forward_backward(X, eps, 1.0, lam=LAM)
+    eng.trace = None
+    if world > 1:
+      parallel.allreduce_mean_(eng.flat_grads)
+    eng.adam_step(LR)
+    eng.sgd_prox_step(WS_LR, t_prox)
+
+  def barrier():
+    if world > 1:
+      torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    step(False)
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    step(True)
+  barrier()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+  if rank == 0:
+    ms = dt / args.steps * 1e3
+    value = GLOBAL_BATCH * args.steps / dt
+    dec_ms = [a.elapsed_time(b) for (name, a, b) in dec_events if name == "decoder"]
+    dec_avg = sum(dec_ms) / max(1, len(dec_ms))
+    dec_flops = decoder_flops_per_row() * rows
+    achieved = dec_flops / (dec_avg * 1e-3) / 1e12 if dec_avg > 0 else 0.0
+    per_kernel = {}
+    for name, a, b in dec_events:
+      per_kernel.setdefault(name, []).append(a.elapsed_time(b))
+    out = {
+      "metric": "oi-VAE train samples/sec (fwd+bwd+prox)", "value": value, "unit": "samples/s",
+      "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+      "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+      "data": "synthetic",
+      "config": {"workload": "synthetic scale-up: G=1024 groups x 64 dims, K=64, H=M=64 two-layer generators, "
+                             "global batch 65536, S=1", "global_batch": GLOBAL_BATCH,
+                 "parallelism": "dp%d" % world, "rows_per_gpu": rows},
+      "roofline": {"bound": "mfma", "kernel": "dec_mfma<64,64,64,64> (grouped decoder fwd+bwd)",
+                   "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                   "avg_launch_ms": dec_avg, "flops_per_launch": dec_flops},
+      "step_model_tflops": (decoder_flops_per_row() + encoder_flops_per_row()) * GLOBAL_BATCH / (ms * 1e-3) / 1e12 / world,
+      "entry_ms": {k: sum(v) / len(v) for k, v in per_kernel.items()},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+  if world > 1:
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

@@ -33,15 +33,9 @@ constexpr int kEncDC = 256;    // X columns staged per step
 
 __global__ __launch_bounds__(256) void enc_fwd_generic(
     const float* __restrict__ X, int64_t B, int D, int K, const float* __restrict__ Wmu,
-    const float* __restrict__ bmu, const float* __restrict__ Wsig, const float* __restrict__ bsig, int S,
-    const float* __restrict__ eps, float c, float sig_off, const float* __restrict__ prior_mu,
-    const float* __restrict__ prior_sigma, int prior_stride, float* __restrict__ mu_q,
-    float* __restrict__ sig_q, float* __restrict__ ea, float* __restrict__ z,
-    double* __restrict__ kl_part) {
+    const float* __restrict__ Wsig, float* __restrict__ pre) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* sX = reinterpret_cast<float*>(smem_raw);            // [kEncRows][kEncDC+1]
-  float* sOut = sX + kEncRows * (kEncDC + 1);                // [kEncRows][2K]
-  __shared__ double sred[256];
   const int J = 2 * K;
   const int tid = threadIdx.x;
   const int r = tid >> 4, jj = tid & 15;
@@ -76,36 +70,47 @@ __global__ __launch_bounds__(256) void enc_fwd_generic(
         }
       }
     }
+    const int64_t b = b0 + r;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int j = jb + jj + 16 * q;
-      if (j < J) sOut[r * J + j] = acc[q];
+      if (j < J && b < B) pre[b * J + j] = acc[q];
     }
   }
-  __syncthreads();
+}
+
+// bias, exp/affine head, reparameterisation and KL over pre[B, 2K]
+__global__ __launch_bounds__(256) void enc_fwd_epilogue(
+    const float* __restrict__ pre, int64_t B, int K, const float* __restrict__ bmu,
+    const float* __restrict__ bsig, int S, const float* __restrict__ eps, float c, float sig_off,
+    const float* __restrict__ prior_mu, const float* __restrict__ prior_sigma, int prior_stride,
+    float* __restrict__ mu_q, float* __restrict__ sig_q, float* __restrict__ ea, float* __restrict__ z,
+    double* __restrict__ kl_part) {
+  __shared__ double sred[256];
+  const int J = 2 * K;
+  const int64_t total = B * K;
   double kl = 0.0;
-  for (int idx = tid; idx < kEncRows * K; idx += 256) {
-    const int rr = idx / K, k = idx - rr * K;
-    const int64_t b = b0 + rr;
-    if (b >= B) continue;
-    const float mu = sOut[rr * J + k] + bmu[k];
-    const float a = sOut[rr * J + K + k] + bsig[k];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / K;
+    const int k = (int)(i - b * K);
+    const float mu = pre[b * J + k] + bmu[k];
+    const float a = pre[b * J + K + k] + bsig[k];
     const float e = expf(a);
     const float sg = e * c + sig_off;
-    const float mp = prior_mu[(int64_t)b * prior_stride + k];
-    const float sp = prior_sigma[(int64_t)b * prior_stride + k];
+    const float mp = prior_mu[b * prior_stride + k];
+    const float sp = prior_sigma[b * prior_stride + k];
     const float dm = mu - mp;
     kl += (double)(-0.5f + (sg * sg + dm * dm) / (2.f * sp * sp) + logf(sp) - logf(sg));
-    mu_q[b * K + k] = mu;
-    sig_q[b * K + k] = sg;
-    ea[b * K + k] = e;
+    mu_q[i] = mu;
+    sig_q[i] = sg;
+    ea[i] = e;
     for (int s = 0; s < S; ++s) {
       const int64_t n = (int64_t)s * B + b;
       z[n * K + k] = mu + sg * eps[n * K + k];
     }
   }
   const double tot = block_sum_double(kl, sred);
-  if (tid == 0) kl_part[blockIdx.x] = tot;
+  if (threadIdx.x == 0) kl_part[blockIdx.x] = tot;
 }
 
 // ------------------------------------------------------------------------------
@@ -442,6 +447,11 @@ static int64_t dec_lds_floats(const oivae_shape_t& s, int R, int DC) {
 
 bool mfma_decoder_applies(const oivae_shape_t& s);          // mfma_decoder.hip
 int mfma_decoder_chunks(const oivae_shape_t& s, int64_t N);  // mfma_decoder.hip
+bool mfma_encoder_applies(const oivae_shape_t& s);           // mfma_encoder.hip
+int launch_encoder_fwd_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, const float* X, int64_t B,
+                            float* pre, hipStream_t st);
+int launch_encoder_bwd_mfma(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X,
+                            const float* dpre, int64_t B, hipStream_t st);
 
 DecPlan plan_decoder(const oivae_shape_t& s, int64_t N) {
   DecPlan pl;
@@ -487,13 +497,22 @@ extern "C" int oivae_encoder_fwd_f32(const oivae_shape_t* shape, const oivae_ten
   Workspace w;
   if (int rc = carve_workspace(*shape, B, S, workspace, workspace_bytes, &w)) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t blocks = (B + kEncRows - 1) / kEncRows;
-  if (blocks > w.n_kl) return fail(OIVAE_E_SHAPE, "oivae_encoder_fwd_f32: batch %lld too large for the generic encoder", (long long)B);
+  float* pre = w.dpre;  // [B, 2K]; the backward pass reuses the buffer for dpre
+  if (mfma_encoder_applies(*shape)) {
+    if (int rc = launch_encoder_fwd_mfma(*shape, params, X, B, pre, st)) return rc;
+  } else {
+    const int64_t blocks = (B + kEncRows - 1) / kEncRows;
+    const size_t lds = sizeof(float) * (size_t)kEncRows * (kEncDC + 1);
+    hipLaunchKernelGGL(enc_fwd_generic, dim3((unsigned)blocks), dim3(256), lds, st, X, B, shape->D, shape->K,
+                       params->enc_Wmu, params->enc_Wsig, pre);
+    OIVAE_LAUNCH_CHECK();
+  }
   OIVAE_HIP_CHECK(hipMemsetAsync(w.kl_part, 0, sizeof(double) * w.n_kl, st));
-  const size_t lds = sizeof(float) * ((size_t)kEncRows * (kEncDC + 1) + (size_t)kEncRows * 2 * shape->K);
-  hipLaunchKernelGGL(enc_fwd_generic, dim3((unsigned)blocks), dim3(256), lds, st, X, B, shape->D, shape->K,
-                     params->enc_Wmu, params->enc_bmu, params->enc_Wsig, params->enc_bsig, S, eps, c, sig_off,
-                     prior_mu, prior_sigma, prior_rows == 1 ? 0 : shape->K, mu_q, sig_q, ea, z, w.kl_part);
+  int64_t eblocks = (B * shape->K + 255) / 256;
+  if (eblocks > 2048) eblocks = 2048;
+  hipLaunchKernelGGL(enc_fwd_epilogue, dim3((unsigned)eblocks), dim3(256), 0, st, pre, B, shape->K,
+                     params->enc_bmu, params->enc_bsig, S, eps, c, sig_off, prior_mu, prior_sigma,
+                     prior_rows == 1 ? 0 : shape->K, mu_q, sig_q, ea, z, w.kl_part);
   OIVAE_LAUNCH_CHECK();
   return OIVAE_OK;
 }
@@ -601,9 +620,13 @@ extern "C" int oivae_encoder_bwd_f32(const oivae_shape_t* shape, const oivae_ten
   hipLaunchKernelGGL(enc_bwd_bias, dim3((unsigned)(2 * s.K)), dim3(256), 0, st, w.dpre, B, s.K, grads->enc_bmu,
                      grads->enc_bsig);
   OIVAE_LAUNCH_CHECK();
-  const dim3 grid((unsigned)((s.D + 63) / 64), (unsigned)((2 * s.K + 31) / 32));
-  hipLaunchKernelGGL(enc_bwd_wgrad_generic, grid, dim3(256), 0, st, X, w.dpre, B, s.D, s.K, grads->enc_Wmu,
-                     grads->enc_Wsig);
-  OIVAE_LAUNCH_CHECK();
+  if (mfma_encoder_applies(s)) {
+    if (int rc = launch_encoder_bwd_mfma(s, grads, X, w.dpre, B, st)) return rc;
+  } else {
+    const dim3 grid((unsigned)((s.D + 63) / 64), (unsigned)((2 * s.K + 31) / 32));
+    hipLaunchKernelGGL(enc_bwd_wgrad_generic, grid, dim3(256), 0, st, X, w.dpre, B, s.D, s.K, grads->enc_Wmu,
+                       grads->enc_Wsig);
+    OIVAE_LAUNCH_CHECK();
+  }
   return OIVAE_OK;
 }

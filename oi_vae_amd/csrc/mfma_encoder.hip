@@ -1,0 +1,284 @@
+// Encoder GEMMs on the fp32 matrix cores of gfx950.
+//
+// Forward: pre[B, 2K] = X[B, D] * [Wmu; Wsig]^T  -- both heads of the encoder
+// (/root/reference/lib/models.py:15-16 with the two nn.Linear of
+// bars_data_oivae.py:66-87) in ONE pass over X, instead of the reference's two
+// separate Linear calls that each re-read X.
+// Backward: [dWmu; dWsig][2K, D] = dpre^T[2K, B] * X[B, D]  -- the encoder weight
+// gradient of loss.backward() (lib/oivae.py:75); no dX is needed.
+//
+// Both are LDS-tiled v_mfma_f32_32x32x2_f32 kernels (exact fp32: the result is an
+// fmaf chain), 4 waves per workgroup, register-staged double buffering with one
+// barrier per 32-deep K-tile.  The MFMA reduction index may be visited in any
+// order, which the forward kernel uses to read both operands with conflict-free
+// 16-byte LDS loads: lane half hh takes the odd/even 4-float chunk of each row.
+// Roofline: MFMA-bound at the scale-up shape (1.1 TFLOP each over 17.2 GB of X).
+#include "common.h"
+
+namespace oivae {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+#define OIVAE_ROW(r, hh) (((r) & 3) + 8 * ((r) >> 2) + 4 * (hh))
+
+// ------------------------------------------------------------------------------
+// forward: pre[b][j] = sum_d X[b][d] * Wcat[j][d]
+//   workgroup tile = (32*WM*WGM) rows x (32*WN*WGN) columns, WGM*WGN = 4 waves
+// ------------------------------------------------------------------------------
+template <int WM, int WN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void enc_fwd_gemm(const float* __restrict__ X, int64_t B, int D, int K,
+                                                    const float* __restrict__ Wmu,
+                                                    const float* __restrict__ Wsig,
+                                                    float* __restrict__ pre) {
+  static_assert(WGM * WGN == 4, "4 waves");
+  constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN, LD = 36;
+  constexpr int A4 = BM * 8 / 256, B4 = BN * 8 / 256;  // float4 loads per thread per tile
+  static_assert(BM * 8 % 256 == 0 && BN * 8 % 256 == 0, "tile/threads");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sA = reinterpret_cast<float*>(smem_raw);  // [2][BM][LD]
+  float* sB = sA + 2 * BM * LD;                    // [2][BN][LD]
+  const int J = 2 * K;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int j0 = blockIdx.y * BN;
+
+  const float* aptr[A4];
+  bool aok[A4];
+  int aoff[A4];
+#pragma unroll
+  for (int i = 0; i < A4; ++i) {
+    const int f = tid + 256 * i, row = f >> 3, c = f & 7;
+    aok[i] = (m0 + row) < B;
+    aptr[i] = X + (aok[i] ? (m0 + row) : 0) * (int64_t)D + 4 * c;
+    aoff[i] = row * LD + 4 * c;
+  }
+  const float* bptr[B4];
+  bool bok[B4];
+  int boff[B4];
+#pragma unroll
+  for (int i = 0; i < B4; ++i) {
+    const int f = tid + 256 * i, row = f >> 3, c = f & 7;
+    const int j = j0 + row;
+    bok[i] = j < J;
+    bptr[i] = (j < K ? Wmu + (int64_t)j * D : Wsig + (int64_t)(bok[i] ? j - K : 0) * D) + 4 * c;
+    boff[i] = row * LD + 4 * c;
+  }
+  f32x4 ra[A4], rb[B4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A4; ++i) ra[i] = aok[i] ? *reinterpret_cast<const f32x4*>(aptr[i] + k0) : (f32x4)(0.f);
+#pragma unroll
+    for (int i = 0; i < B4; ++i) rb[i] = bok[i] ? *reinterpret_cast<const f32x4*>(bptr[i] + k0) : (f32x4)(0.f);
+  };
+  auto lstore = [&](int buf) {
+    float* a = sA + buf * BM * LD;
+    float* b = sB + buf * BN * LD;
+#pragma unroll
+    for (int i = 0; i < A4; ++i) *reinterpret_cast<f32x4*>(a + aoff[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B4; ++i) *reinterpret_cast<f32x4*>(b + boff[i]) = rb[i];
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x16)(0.f);
+
+  const int T = D / 32;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    if (t + 1 < T) gload((t + 1) * 32);
+    const float* a = sA + (t & 1) * BM * LD + (wm * WM * 32 + l31) * LD + 4 * hh;
+    const float* b = sB + (t & 1) * BN * LD + (wn * WN * 32 + l31) * LD + 4 * hh;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 fa[WM], fb[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LD + 8 * c);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LD + 8 * c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < T) lstore((t + 1) & 1);
+    __syncthreads();
+  }
+  // C[i = row b][j]: lane holds column j, registers hold rows
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = j0 + (wn * WN + j) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + (wm * WM + i) * 32 + OIVAE_ROW(r, hh);
+        if (row < B && col < J) pre[row * J + col] = acc[i][j][r];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------
+// backward: dW[j][d] = sum_b dpre[b][j] * X[b][d]
+//   workgroup tile = (32*TJ) rows j x 256 columns d; each wave owns all rows x 64 columns
+// ------------------------------------------------------------------------------
+template <int TJ>
+__global__ __launch_bounds__(256) void enc_bwd_gemm(const float* __restrict__ X, const float* __restrict__ dpre,
+                                                    int64_t B, int D, int K, float* __restrict__ dWmu,
+                                                    float* __restrict__ dWsig) {
+  constexpr int BJ = 32 * TJ, BD = 256;
+  constexpr int P4 = 32 * BJ / 4 / 256;  // float4 per thread for the dpre tile (BJ=128: 4, 64: 2, 32: 1)
+  static_assert(32 * BJ / 4 % 256 == 0, "tile/threads");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sX = reinterpret_cast<float*>(smem_raw);  // [2][32][BD]
+  float* sP = sX + 2 * 32 * BD;                    // [2][32][BJ]
+  const int J = 2 * K;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int d0 = blockIdx.x * BD, j0 = blockIdx.y * BJ;
+
+  // X tile [32][256]: 8 float4 per thread; thread -> (row = f/64, c = f%64)
+  f32x4 rx[8], rp[P4];
+  auto gload = [&](int64_t b0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = tid + 256 * i, row = f >> 6, c = f & 63;
+      const int64_t b = b0 + row;
+      const int d = d0 + 4 * c;
+      rx[i] = (b < B && d < D) ? *reinterpret_cast<const f32x4*>(X + b * (int64_t)D + d) : (f32x4)(0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < P4; ++i) {
+      const int f = tid + 256 * i, row = f / (BJ / 4), c = f % (BJ / 4);
+      const int64_t b = b0 + row;
+      const int j = j0 + 4 * c;
+      rp[i] = (b < B && j < J) ? *reinterpret_cast<const f32x4*>(dpre + b * (int64_t)J + j) : (f32x4)(0.f);
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* x = sX + buf * 32 * BD;
+    float* p = sP + buf * 32 * BJ;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = tid + 256 * i;
+      *reinterpret_cast<f32x4*>(x + 4 * f) = rx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < P4; ++i) {
+      const int f = tid + 256 * i;
+      *reinterpret_cast<f32x4*>(p + 4 * f) = rp[i];
+    }
+  };
+
+  f32x16 acc[TJ][2];
+#pragma unroll
+  for (int i = 0; i < TJ; ++i) { acc[i][0] = (f32x16)(0.f); acc[i][1] = (f32x16)(0.f); }
+
+  const int64_t T = (B + 31) / 32;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int64_t t = 0; t < T; ++t) {
+    if (t + 1 < T) gload((t + 1) * 32);
+    const float* p = sP + (t & 1) * 32 * BJ + l31;
+    const float* x = sX + (t & 1) * 32 * BD + wave * 64 + l31;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int row = 2 * s + hh;
+      float fa[TJ], fb[2];
+#pragma unroll
+      for (int i = 0; i < TJ; ++i) fa[i] = p[row * BJ + 32 * i];
+      fb[0] = x[row * BD];
+      fb[1] = x[row * BD + 32];
+#pragma unroll
+      for (int i = 0; i < TJ; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[0], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[1], acc[i][1], 0, 0, 0);
+      }
+    }
+    if (t + 1 < T) lstore((t + 1) & 1);
+    __syncthreads();
+  }
+  // C[i = j][col = d]
+#pragma unroll
+  for (int i = 0; i < TJ; ++i)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int d = d0 + wave * 64 + 32 * q + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = j0 + 32 * i + OIVAE_ROW(r, hh);
+        if (d < D && j < J) {
+          if (j < K) dWmu[(int64_t)j * D + d] = acc[i][q][r];
+          else dWsig[(int64_t)(j - K) * D + d] = acc[i][q][r];
+        }
+      }
+    }
+}
+
+bool mfma_encoder_applies(const oivae_shape_t& s) {
+  return (s.D % 32 == 0) && ((2 * s.K) % 32 == 0);
+}
+
+template <int WM, int WN, int WGM, int WGN>
+static int launch_fwd(const float* X, int64_t B, int D, int K, const float* Wmu, const float* Wsig, float* pre,
+                      hipStream_t st) {
+  constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
+  const size_t lds = sizeof(float) * 2 * (BM + BN) * 36;
+  OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_fwd_gemm<WM, WN, WGM, WGN>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const dim3 grid((unsigned)((B + BM - 1) / BM), (unsigned)((2 * K + BN - 1) / BN));
+  hipLaunchKernelGGL((enc_fwd_gemm<WM, WN, WGM, WGN>), grid, dim3(256), lds, st, X, B, D, K, Wmu, Wsig, pre);
+  OIVAE_LAUNCH_CHECK();
+  return OIVAE_OK;
+}
+
+int launch_encoder_fwd_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, const float* X, int64_t B,
+                            float* pre, hipStream_t st) {
+  if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(params->enc_Wmu) & 15) ||
+      (reinterpret_cast<uintptr_t>(params->enc_Wsig) & 15))
+    return fail(OIVAE_E_ARG, "MFMA encoder: X, Wmu, Wsig must be 16-byte aligned");
+  const int J = 2 * s.K;
+  const bool big = B >= 256 * 192;  // enough 256-row tiles to fill the chip
+  if (J % 128 == 0) {
+    if (big) return launch_fwd<2, 4, 4, 1>(X, B, s.D, s.K, params->enc_Wmu, params->enc_Wsig, pre, st);
+    return launch_fwd<1, 2, 2, 2>(X, B, s.D, s.K, params->enc_Wmu, params->enc_Wsig, pre, st);
+  }
+  if (J % 64 == 0) {
+    if (big) return launch_fwd<2, 2, 4, 1>(X, B, s.D, s.K, params->enc_Wmu, params->enc_Wsig, pre, st);
+    return launch_fwd<1, 1, 2, 2>(X, B, s.D, s.K, params->enc_Wmu, params->enc_Wsig, pre, st);
+  }
+  return launch_fwd<1, 1, 4, 1>(X, B, s.D, s.K, params->enc_Wmu, params->enc_Wsig, pre, st);
+}
+
+template <int TJ>
+static int launch_bwd(const float* X, const float* dpre, int64_t B, int D, int K, float* dWmu, float* dWsig,
+                      hipStream_t st) {
+  const size_t lds = sizeof(float) * 2 * 32 * (256 + 32 * TJ);
+  OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_gemm<TJ>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const dim3 grid((unsigned)((D + 255) / 256), (unsigned)((2 * K + 32 * TJ - 1) / (32 * TJ)));
+  hipLaunchKernelGGL((enc_bwd_gemm<TJ>), grid, dim3(256), lds, st, X, dpre, B, D, K, dWmu, dWsig);
+  OIVAE_LAUNCH_CHECK();
+  return OIVAE_OK;
+}
+
+int launch_encoder_bwd_mfma(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X,
+                            const float* dpre, int64_t B, hipStream_t st) {
+  if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(dpre) & 15))
+    return fail(OIVAE_E_ARG, "MFMA encoder: X and dpre must be 16-byte aligned");
+  const int J = 2 * s.K;
+  if (J % 128 == 0) return launch_bwd<4>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st);
+  if (J % 64 == 0) return launch_bwd<2>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st);
+  return launch_bwd<1>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st);
+}
+
+}  // namespace oivae

@@ -111,6 +111,19 @@ class Engine:
     self.adam_m: Optional[torch.Tensor] = None
     self.adam_v: Optional[torch.Tensor] = None
     self.adam_t = 0
+    # optional per-entry-point timing: a list that receives (name, start_event, end_event)
+    self.trace = None
+
+  def _timed(self, name, fn):
+    if self.trace is None:
+      return fn()
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record(torch.cuda.current_stream(self.device))
+    rc = fn()
+    b.record(torch.cuda.current_stream(self.device))
+    self.trace.append((name, a, b))
+    return rc
 
   # ---- storage ---------------------------------------------------------------
   def _view(self, flat, name, shape):
@@ -237,19 +250,22 @@ class Engine:
       st = self._stream()
       L = self.lib
       sh, pt, gt = ctypes.byref(self._shape), ctypes.byref(self._pt), ctypes.byref(self._gt)
-      _lib.check(L.oivae_encoder_fwd_f32(sh, pt, X.data_ptr(), B, S, eps.data_ptr(), float(c), float(sig_off),
-                                         prior_mu.data_ptr(), prior_sigma.data_ptr(), prior_rows,
-                                         mu_q.data_ptr(), sig_q.data_ptr(), ea.data_ptr(), z.data_ptr(),
-                                         ws.data_ptr(), self._ws_bytes, st), "oivae_encoder_fwd_f32")
-      _lib.check(L.oivae_decoder_fwd_bwd_f32(sh, pt, gt, X.data_ptr(), B, S, z.data_ptr(), float(gen_sig_off),
-                                             dz.data_ptr(), ws.data_ptr(), self._ws_bytes, st),
-                 "oivae_decoder_fwd_bwd_f32")
-      _lib.check(L.oivae_encoder_bwd_f32(sh, gt, X.data_ptr(), B, S, eps.data_ptr(), float(c),
-                                         prior_mu.data_ptr(), prior_sigma.data_ptr(), prior_rows,
-                                         mu_q.data_ptr(), sig_q.data_ptr(), ea.data_ptr(), dz.data_ptr(),
-                                         ws.data_ptr(), self._ws_bytes, st), "oivae_encoder_bwd_f32")
-      _lib.check(L.oivae_finalize_f32(sh, pt, gt, B, S, float(sigma_theta), float(lam), self.scalars.data_ptr(),
-                                      ws.data_ptr(), self._ws_bytes, st), "oivae_finalize_f32")
+      _lib.check(self._timed("encoder_fwd", lambda: L.oivae_encoder_fwd_f32(
+        sh, pt, X.data_ptr(), B, S, eps.data_ptr(), float(c), float(sig_off),
+        prior_mu.data_ptr(), prior_sigma.data_ptr(), prior_rows,
+        mu_q.data_ptr(), sig_q.data_ptr(), ea.data_ptr(), z.data_ptr(),
+        ws.data_ptr(), self._ws_bytes, st)), "oivae_encoder_fwd_f32")
+      _lib.check(self._timed("decoder", lambda: L.oivae_decoder_fwd_bwd_f32(
+        sh, pt, gt, X.data_ptr(), B, S, z.data_ptr(), float(gen_sig_off),
+        dz.data_ptr(), ws.data_ptr(), self._ws_bytes, st)), "oivae_decoder_fwd_bwd_f32")
+      _lib.check(self._timed("encoder_bwd", lambda: L.oivae_encoder_bwd_f32(
+        sh, gt, X.data_ptr(), B, S, eps.data_ptr(), float(c),
+        prior_mu.data_ptr(), prior_sigma.data_ptr(), prior_rows,
+        mu_q.data_ptr(), sig_q.data_ptr(), ea.data_ptr(), dz.data_ptr(),
+        ws.data_ptr(), self._ws_bytes, st)), "oivae_encoder_bwd_f32")
+      _lib.check(self._timed("finalize", lambda: L.oivae_finalize_f32(
+        sh, pt, gt, B, S, float(sigma_theta), float(lam), self.scalars.data_ptr(),
+        ws.data_ptr(), self._ws_bytes, st)), "oivae_finalize_f32")
     return dict(mu_q=mu_q, sig_q=sig_q, z=z, scalars=self.scalars, X=X, eps=eps)
 
   def _const(self, name, val):
