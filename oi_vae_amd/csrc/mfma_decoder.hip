@@ -32,6 +32,7 @@
 // v_mfma_f32_32x32x2_f32 per wave-tile.
 #include "common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace oivae {
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(256) void dec_mfma(MfmaDecArgs a) {
 }
 
 bool mfma_decoder_applies(const oivae_shape_t& s) {
+  if (getenv("OIVAE_FORCE_GENERIC")) return false;  // test hook: cross-check the two kernel families
   if (s.gen_type != OIVAE_GEN_MLP) return false;
   const int dg = s.uniform_group_dim;
   const bool all64 = (s.K == 64 && s.H == 64 && s.M == 64 && dg == 64);

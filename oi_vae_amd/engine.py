@@ -113,6 +113,8 @@ class Engine:
     self.adam_t = 0
     # optional per-entry-point timing: a list that receives (name, start_event, end_event)
     self.trace = None
+    self.gen_sig_off = 1e-3
+    self.bound = []  # (user tensor, grad view) pairs set by adopt()
 
   def _timed(self, name, fn):
     if self.trace is None:

@@ -1,0 +1,159 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports what
+include/oivae_hip.h declares, the product refuses to run without a GPU, model
+recognition reads the reference-style heads correctly, and the data-parallel
+gradient mean over two gloo ranks equals the global-batch gradient."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+  from oi_vae_amd import _lib
+  header = open(os.path.join(ROOT, "include", "oivae_hip.h")).read()
+  declared = sorted(set(re.findall(r"\b(oivae_[a-z0-9_]+)\s*\(", header)))
+  assert declared == sorted(_lib.SYMBOLS)
+  L = _lib.load()
+  for sym in declared:
+    assert hasattr(L, sym), sym
+  assert b"gfx950" in L.oivae_version()
+
+
+def test_product_never_imports_the_oracle():
+  pkg = os.path.join(ROOT, "oi_vae_amd")
+  for dirpath, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith((".py", ".hip", ".h", ".cpp")):
+        text = open(os.path.join(dirpath, f)).read()
+        assert "import oracle" not in text and "from oracle" not in text, f
+        assert "prox_oracle" not in text or f.endswith(".hip"), f
+
+
+def _bars_model(holder, K=8):
+  import oi_vae_amd as oi
+  inference_net = oi.NormalNet(
+    mu_net=torch.nn.Sequential(torch.nn.Linear(64, K)),
+    sigma_net=torch.nn.Sequential(torch.nn.Linear(64, K), oi.Lambda(torch.exp),
+                                  oi.Lambda(lambda x: x * holder["c"] + 1e-3)))
+
+  def make_gen():
+    log_sigma = torch.log(1e-2 * torch.ones(8)).requires_grad_(True)
+    return oi.NormalNet(mu_net=torch.nn.Linear(1, 8),
+                        sigma_net=oi.Lambda(lambda x, ls: torch.exp(ls.expand(x.size(0), -1)) + 1e-3,
+                                            extra_args=(log_sigma,)))
+  gen = oi.BayesianGroupLassoGenerator([make_gen() for _ in range(8)], group_input_dim=1, dim_z=K)
+  return inference_net, gen
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_gpu():
+  import oi_vae_amd as oi
+  holder = {"c": 0.1}
+  inf, gen = _bars_model(holder)
+  with pytest.raises(oi.OivaeError):
+    oi.OIVAE(inf, gen, oi.Normal(torch.zeros(1, 8), torch.ones(1, 8)), oi.NormalPriorTheta(1.0), 1.0, [])
+  with pytest.raises(oi.OivaeError):
+    gen.proximal_step(0.1)
+  with pytest.raises(oi.OivaeError):
+    oi.Engine(oi.ModelSpec(D=64, K=8, H=1, group_dims=[8] * 8, gen_type="linear"))
+
+
+def test_head_probing_reads_the_lambda_constants():
+  from oi_vae_amd import adopt
+  holder = {"c": 0.1}
+  inf, gen = _bars_model(holder)
+  c, off = adopt.probe_encoder_head(inf)
+  assert abs(c - 0.1) < 1e-15 and abs(off - 1e-3) < 1e-15
+  holder["c"] = 1  # the scripts flip stddev_multiple after 1000 iterations (bars_data_oivae.py:258-259)
+  c, off = adopt.probe_encoder_head(inf)
+  assert abs(c - 1.0) < 1e-15
+  ls, goff = adopt._probe_gen_sigma(gen.group_generators[0].sigma_net, 8)
+  assert abs(goff - 1e-3) < 1e-15 and ls.numel() == 8
+  assert adopt._gen_structure(gen.group_generators[0])[0] == "linear"
+
+
+def test_unsupported_heads_are_refused():
+  import oi_vae_amd as oi
+  from oi_vae_amd import adopt
+  bad = oi.NormalNet(mu_net=torch.nn.Sequential(torch.nn.Linear(4, 2)),
+                     sigma_net=torch.nn.Sequential(torch.nn.Linear(4, 2), oi.Lambda(torch.sigmoid)))
+  with pytest.raises(oi.OivaeError):
+    adopt.probe_encoder_head(bad)
+  g = oi.NormalNet(mu_net=torch.nn.Sequential(torch.nn.Linear(2, 4), torch.nn.ReLU(), torch.nn.Linear(4, 3)),
+                   sigma_net=None)
+  with pytest.raises(oi.OivaeError):
+    adopt._gen_structure(g)
+
+
+def test_modelspec_validation():
+  import oi_vae_amd as oi
+  with pytest.raises(ValueError):
+    oi.ModelSpec(D=10, K=2, H=1, group_dims=[4, 4], gen_type="linear")
+  with pytest.raises(ValueError):
+    oi.ModelSpec(D=8, K=2, H=1, group_dims=[4, 4], gen_type="mlp")
+  s = oi.ModelSpec(D=8, K=2, H=3, group_dims=[5, 3], gen_type="mlp", M=7)
+  assert s.seg_shapes()["gen_W2"] == (8, 7) and s.seg_shapes()["gen_W1"] == (2, 7, 3)
+
+
+_DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from oracle import oivae_oracle as O
+from oi_vae_amd import parallel
+rank = int(sys.argv[1]); world = 2
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[2]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.set_num_threads(1)
+spec = dict(D=24, K=16, H=8, M=24, gen_type="mlp", group_dims=[5, 12, 7])
+params = O.init_params(spec, seed=3)
+rng = np.random.default_rng(0)
+B = 32
+X = rng.random((B, 24), dtype=np.float32); eps = rng.standard_normal((2, B, 16)).astype(np.float32)
+
+def flat_grads(Xs, es):
+  m = O.OracleModel(spec, params)
+  t = O.forward_terms(m, torch.from_numpy(Xs), torch.from_numpy(es), 0.5, 1.0, 1.0)
+  t["loss"].backward()
+  g = m.export_grads()
+  parts = [g[k].ravel() if not isinstance(g[k], list) else np.concatenate([a.ravel() for a in g[k]]) for k in sorted(g)]
+  sc = np.array([float(t[k]) for k in ("z_kl", "loglik_term", "logprob_theta", "logprob_W", "loss", "elbo")], np.float32)
+  return np.concatenate(parts), sc
+
+lo, hi = parallel.shard_rows(B, rank, world)
+g_local, sc_local = flat_grads(X[lo:hi], eps[:, lo:hi])
+g = torch.from_numpy(g_local.copy()); sc = torch.from_numpy(sc_local.copy())
+parallel.allreduce_mean_(g); parallel.reduce_scalars_(sc)
+g_full, sc_full = flat_grads(X, eps)
+err = np.max(np.abs(g.numpy() - g_full)) / np.max(np.abs(g_full))
+serr = np.max(np.abs(sc.numpy() - sc_full) / np.maximum(np.abs(sc_full), 1))
+assert err < 2e-6, err
+assert serr < 2e-6, serr
+assert parallel.is_active()
+dist.destroy_process_group()
+print("rank", rank, "ok", err, serr)
+'''
+
+
+def test_data_parallel_mean_equals_global_batch_gradient_gloo(tmp_path):
+  script = tmp_path / "dp_worker.py"
+  script.write_text(_DP_WORKER % {"root": ROOT})
+  port = str(29500 + (os.getpid() % 2000))
+  procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT, text=True) for r in range(2)]
+  outs = [p.communicate(timeout=240)[0] for p in procs]
+  for p, o in zip(procs, outs):
+    assert p.returncode == 0, o
+
+
+def test_shard_rows_rejects_uneven_split():
+  from oi_vae_amd import parallel
+  assert parallel.shard_rows(64, 1, 2) == (32, 64)
+  with pytest.raises(ValueError):
+    parallel.shard_rows(65, 0, 2)
