@@ -29,6 +29,17 @@ LR, WS_LR, LAM = 1e-3, 1e-4, 1.0
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 
 
+def pmc_traffic():
+  """HBM bytes per decoder launch from the committed rocprofv3 PMC passes
+  (profiles/README.md); counters cannot be read from inside this process."""
+  try:
+    d = json.load(open(os.path.join(ROOT, "profiles", "pmc_per_kernel_latest.json")))
+    k = next(v for n, v in d.items() if "dec_mfma" in n)
+    return k["hbm_read_bytes_corrected"] + k["hbm_write_bytes"]
+  except Exception:
+    return None
+
+
 def decoder_flops_per_row():
   # fwd + dgrad + wgrad of the three per-group products (SURVEY.md section 8d)
   return 3 * G * (2 * K * H + 2 * H * M + 2 * M * DG)
@@ -60,7 +71,43 @@ def init_engine(device, batch_rows, seed):
   return eng, X
 
 
-def cpu_baseline(batch=256):
+def prox_roofline(device):
+  """Secondary measurement (BASELINE.json configs[4], wide-prox stress): the fused
+  SGD + proximal kernel on G=8192 x K=256 x H=8, threshold at the median row norm
+  (about half of the rows die).  HBM-bound: 12 B/element (Ws read+write, dWs read)
+  + 5 B/row (mask byte + norm)."""
+  import ctypes
+  from oi_vae_amd import _lib
+  L = _lib.init_device(device.index)
+  Gp, Kp, Hp = 8192, 256, 8
+  gen = torch.Generator(device=device).manual_seed(3)
+  W0 = torch.randn(Gp, Kp, Hp, generator=gen, device=device)
+  dW = torch.randn(Gp, Kp, Hp, generator=gen, device=device)
+  t = float(torch.sqrt((W0 ** 2).sum(-1)).median())
+  mask = torch.zeros(Gp, Kp, dtype=torch.uint8, device=device)
+  norms = torch.zeros(Gp, Kp, dtype=torch.float32, device=device)
+  st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+  reps = 20
+  Ws = [W0.clone() for _ in range(reps + 2)]  # fresh input per launch so every launch does the same work
+  evs = []
+  for i, W in enumerate(Ws):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    _lib.check(L.oivae_sgd_prox_f32(W.data_ptr(), dW.data_ptr(), Gp * Kp, Hp, 1e-4, t, 1, mask.data_ptr(),
+                                    norms.data_ptr(), st), "oivae_sgd_prox_f32")
+    b.record()
+    evs.append((a, b))
+  torch.cuda.synchronize()
+  ms = sorted(a.elapsed_time(b) for a, b in evs[2:])
+  avg = sum(ms) / len(ms)
+  nbytes = 12 * Gp * Kp * Hp + 5 * Gp * Kp
+  return {"workload": "wide-prox: SGD+proximal step on Ws [8192,256,8], t = median row norm",
+          "bound": "hbm", "achieved": nbytes / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+          "frac": nbytes / (avg * 1e-3) / 1e9 / 8000.0, "avg_launch_ms": avg, "bytes_per_launch": nbytes,
+          "zeroed_fraction": float(mask.float().mean())}
+
+
+def cpu_baseline(batch=1024, steps=2):
   """The oracle (CPU restatement with the reference's per-group loop) on the host
   cores, same shapes at a reduced batch; reported, not a target."""
   import numpy as np
@@ -73,10 +120,12 @@ def cpu_baseline(batch=256):
   X = rng.random((batch, spec["D"]), dtype=np.float32)
   eps = rng.standard_normal((1, batch, K)).astype(np.float32)
   t0 = time.perf_counter()
-  tr.step(X, eps, c=1.0, prox_step_size=WS_LR * LAM, want_grads=False)
+  for _ in range(steps):
+    tr.step(X, eps, c=1.0, prox_step_size=WS_LR * LAM, want_grads=False)
   dt = time.perf_counter() - t0
-  return {"value": batch / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-          "sample": "1 oracle step of the same shapes at batch %d (%.1f s)" % (batch, dt)}
+  return {"value": batch * steps / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+          "sample": "%d oracle steps (per-group loop, torch CPU autograd + Adam/SGD + prox) of the same shapes "
+                    "at batch %d instead of 65536 (%.1f s)" % (steps, batch, dt)}
 
 
 def main():
@@ -156,11 +205,13 @@ def main():
                  "parallelism": "dp%d" % world, "rows_per_gpu": rows},
       "roofline": {"bound": "mfma", "kernel": "dec_mfma<64,64,64,64> (grouped decoder fwd+bwd)",
                    "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                   "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                   "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic() if world == 1 else None,
                    "avg_launch_ms": dec_avg, "flops_per_launch": dec_flops},
       "step_model_tflops": (decoder_flops_per_row() + encoder_flops_per_row()) * GLOBAL_BATCH / (ms * 1e-3) / 1e12 / world,
       "entry_ms": {k: sum(v) / len(v) for k, v in per_kernel.items()},
     }
+    if world == 1:
+      out["prox_roofline"] = prox_roofline(device)
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

@@ -83,7 +83,8 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
   w->theta_part = reinterpret_cast<double*>(take(sizeof(double) * 1024));
   w->n_pen = 1024;
   w->pen_part = reinterpret_cast<double*>(take(sizeof(double) * 1024));
-  w->dpre = reinterpret_cast<float*>(take(sizeof(float) * B * 2 * s.K));
+  w->enc_splits = mfma_encoder_fwd_splits(s, B);
+  w->dpre = reinterpret_cast<float*>(take(sizeof(float) * B * 2 * s.K * w->enc_splits));
   w->n_chunks = plan.chunks;
   w->p_dec = L.total;
   w->slab = reinterpret_cast<float*>(take(plan.chunks > 1 ? sizeof(float) * L.total * plan.chunks : 0));

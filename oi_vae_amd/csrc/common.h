@@ -40,13 +40,15 @@ struct Workspace {
   double* ll_part;      int32_t n_ll;      // one per decoder block
   double* theta_part;   int32_t n_theta;   // weight-prior partials
   double* pen_part;     int32_t n_pen;     // penalty partials
-  float*  dpre;                            // [B, 2K] encoder pre-activation grads
+  float*  dpre;                            // [enc_splits, B, 2K] pre-activation partials (fwd), then [B, 2K] their grads (bwd)
+  int32_t enc_splits;
   float*  slab;         int32_t n_chunks;  // [n_chunks, P_dec] decoder grad partials (n_chunks > 1)
   int64_t p_dec;                           // floats per decoder-grad slab
   int64_t total_bytes;
 };
 
-constexpr int kMaxPartials = 16384;  // cap on per-kernel block counts that emit partials
+constexpr int kMaxPartials = 16384;
+constexpr int kMaxEncSplits = 8;     // split-K partial images of the encoder pre-activations  // cap on per-kernel block counts that emit partials
 
 // sizes of the decoder parameter block, in floats, in slab order:
 // [gen_W1 | gen_b1 | gen_W2 | gen_b2 | log_sigma | Ws]
@@ -82,6 +84,7 @@ DecPlan plan_decoder(const oivae_shape_t& s, int64_t N);
 int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, int64_t bytes,
                     Workspace* out);
 int check_shape(const oivae_shape_t* s);
+int mfma_encoder_fwd_splits(const oivae_shape_t& s, int64_t B);  // mfma_encoder.hip
 void launch_slab_reduce(const float* slab, int64_t P, int chunks, float* dst, int64_t seg_off, int64_t seg_n,
                         unsigned blocks, hipStream_t st);
 

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void enc_fwd_generic(
 
 // bias, exp/affine head, reparameterisation and KL over pre[B, 2K]
 __global__ __launch_bounds__(256) void enc_fwd_epilogue(
-    const float* __restrict__ pre, int64_t B, int K, const float* __restrict__ bmu,
+    const float* __restrict__ pre, int nsplit, int64_t B, int K, const float* __restrict__ bmu,
     const float* __restrict__ bsig, int S, const float* __restrict__ eps, float c, float sig_off,
     const float* __restrict__ prior_mu, const float* __restrict__ prior_sigma, int prior_stride,
     float* __restrict__ mu_q, float* __restrict__ sig_q, float* __restrict__ ea, float* __restrict__ z,
@@ -93,8 +93,13 @@ __global__ __launch_bounds__(256) void enc_fwd_epilogue(
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t b = i / K;
     const int k = (int)(i - b * K);
-    const float mu = pre[b * J + k] + bmu[k];
-    const float a = pre[b * J + K + k] + bsig[k];
+    float pm = pre[b * J + k], pa = pre[b * J + K + k];
+    for (int sp = 1; sp < nsplit; ++sp) {  // split-K partial images, summed in index order
+      pm += pre[(int64_t)sp * B * J + b * J + k];
+      pa += pre[(int64_t)sp * B * J + b * J + K + k];
+    }
+    const float mu = pm + bmu[k];
+    const float a = pa + bsig[k];
     const float e = expf(a);
     const float sg = e * c + sig_off;
     const float mp = prior_mu[b * prior_stride + k];
@@ -510,7 +515,7 @@ extern "C" int oivae_encoder_fwd_f32(const oivae_shape_t* shape, const oivae_ten
   OIVAE_HIP_CHECK(hipMemsetAsync(w.kl_part, 0, sizeof(double) * w.n_kl, st));
   int64_t eblocks = (B * shape->K + 255) / 256;
   if (eblocks > 2048) eblocks = 2048;
-  hipLaunchKernelGGL(enc_fwd_epilogue, dim3((unsigned)eblocks), dim3(256), 0, st, pre, B, shape->K,
+  hipLaunchKernelGGL(enc_fwd_epilogue, dim3((unsigned)eblocks), dim3(256), 0, st, pre, w.enc_splits, B, shape->K,
                      params->enc_bmu, params->enc_bsig, S, eps, c, sig_off, prior_mu, prior_sigma,
                      prior_rows == 1 ? 0 : shape->K, mu_q, sig_q, ea, z, w.kl_part);
   OIVAE_LAUNCH_CHECK();

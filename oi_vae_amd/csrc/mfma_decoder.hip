@@ -419,6 +419,319 @@ __global__ __launch_bounds__(256) void dec_mfma(MfmaDecArgs a) {
   }
 }
 
+
+// ==============================================================================
+// v2 of the all-64 kernel: same math and data flow as dec_mfma<64,64,64,64>, with
+// the instruction stream laid out by hand so that the matrix pipe never waits:
+//   * every MFMA's LDS operand is fetched two k-steps ahead (counted lgkmcnt);
+//   * each product is split per 32x32 output tile so that the element-wise work
+//     on a finished tile (tanh, residual epilogue, (1-t^2) scaling), the LDS image
+//     stores, the column sums, the dz atomics and the next tile's global loads
+//     are issued one small chunk per MFMA slot, under the shadow of the 64-cycle
+//     MFMAs of the neighbouring tile (one wave per SIMD issues in order);
+//   * accumulators start from an inline zero C operand instead of v_mov chains;
+//   * x and z of the next row tile are prefetched as soon as their registers die.
+// sched_barrier(0) after every k-step pins this order against the scheduler.
+// ==============================================================================
+#define OIVAE_SB() __builtin_amdgcn_sched_barrier(0)
+#define OIVAE_ROWC(r) (((r) & 3) + 8 * ((r) >> 2))
+
+__device__ __forceinline__ f32x16 mf32(float a_, float b_, f32x16 c_) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, c_, 0, 0, 0);
+}
+
+// one output tile, NK k-steps; wf(s) = LDS weight operand, bf(s) = register operand, vf(s) = VALU chunk
+template <int NK, bool FRESH, class WF, class BF, class VF>
+__device__ __forceinline__ void phase1(f32x16& acc, WF wf, BF bf, VF vf) {
+  float w[NK];
+  w[0] = wf(0); w[1] = wf(1); w[2] = wf(2);
+#pragma unroll
+  for (int s = 0; s < NK; ++s) {
+    if (s + 3 < NK) w[s + 3] = wf(s + 3);
+    vf(s);
+    acc = mf32(w[s], bf(s), (FRESH && s == 0) ? (f32x16)(0.f) : acc);
+    OIVAE_SB();
+  }
+}
+
+// two output tiles sharing the register operand: acc0 += w0*b, acc1 += w1*b; MFMA slot u = 2s+t
+template <int NK, bool FRESH, class WF, class BF, class VF>
+__device__ __forceinline__ void phase2w(f32x16& acc0, f32x16& acc1, WF wf, BF bf, VF vf) {
+  float w[NK][2];
+  w[0][0] = wf(0, 0); w[0][1] = wf(0, 1); w[1][0] = wf(1, 0); w[1][1] = wf(1, 1);
+#pragma unroll
+  for (int s = 0; s < NK; ++s) {
+    if (s + 2 < NK) { w[s + 2][0] = wf(s + 2, 0); w[s + 2][1] = wf(s + 2, 1); }
+    const float b = bf(s);
+    vf(2 * s);
+    acc0 = mf32(w[s][0], b, (FRESH && s == 0) ? (f32x16)(0.f) : acc0);
+    vf(2 * s + 1);
+    acc1 = mf32(w[s][1], b, (FRESH && s == 0) ? (f32x16)(0.f) : acc1);
+    OIVAE_SB();
+  }
+}
+
+// weight-gradient step: both operands come from the wave's LDS images.
+// acc0 += af0(s)*bf0(s), acc1 += af1(s)*bf1(s)   (callers pass identical af or bf for the shared side)
+template <int NK, class AF0, class AF1, class BF0, class BF1, class VF>
+__device__ __forceinline__ void phasewg(f32x16& acc0, f32x16& acc1, AF0 af0, AF1 af1, BF0 bf0, BF1 bf1, VF vf) {
+  float wa0[NK], wa1[NK], wb0[NK], wb1[NK];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) { wa0[s] = af0(s); wa1[s] = af1(s); wb0[s] = bf0(s); wb1[s] = bf1(s); }
+#pragma unroll
+  for (int s = 0; s < NK; ++s) {
+    if (s + 2 < NK) { wa0[s + 2] = af0(s + 2); wa1[s + 2] = af1(s + 2); wb0[s + 2] = bf0(s + 2); wb1[s + 2] = bf1(s + 2); }
+    vf(2 * s);
+    acc0 = mf32(wa0[s], wb0[s], acc0);
+    vf(2 * s + 1);
+    acc1 = mf32(wa1[s], wb1[s], acc1);
+    OIVAE_SB();
+  }
+}
+
+__global__ __launch_bounds__(256) void dec_mfma64_v2(MfmaDecArgs a) {
+  constexpr int K = 64, H = 64, M = 64, DG = 64;
+  constexpr int LW = 65, LDB = 68;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sWs = reinterpret_cast<float*>(smem_raw);
+  float* sW1 = sWs + K * LW;
+  float* sW2 = sW1 + M * LW;
+  float* sb1 = sW2 + DG * LW;
+  float* sb2 = sb1 + M;
+  float* sIsig = sb2 + DG;
+  float* sC2 = sIsig + DG;
+  float* sAct = sC2 + DG;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int g = blockIdx.x, chunk = blockIdx.y, nchunks = gridDim.y;
+  {
+    const float* Wsg = a.Ws + (int64_t)g * K * H;
+    for (int i = tid; i < K * H; i += 256) sWs[(i / H) * LW + (i % H)] = Wsg[i];
+    const float* W1g = a.W1 + (int64_t)g * M * H;
+    for (int i = tid; i < M * H; i += 256) sW1[(i / H) * LW + (i % H)] = W1g[i];
+    const float* W2g = a.W2 + (int64_t)g * DG * M;
+    for (int i = tid; i < DG * M; i += 256) sW2[(i / M) * LW + (i % M)] = W2g[i];
+    for (int i = tid; i < M; i += 256) sb1[i] = a.b1[(int64_t)g * M + i];
+    for (int i = tid; i < DG; i += 256) {
+      const float sg = expf(a.ls[(int64_t)g * DG + i]) + a.sig_off;
+      sb2[i] = a.b2[(int64_t)g * DG + i];
+      sIsig[i] = 1.0f / sg;
+      sC2[i] = a.inv / sg;
+    }
+  }
+  __syncthreads();
+
+  float* bufA = sAct + wave * (2 * 32 * LDB);
+  float* bufB = bufA + 32 * LDB;
+  // per-lane operand bases
+  const float* pWs_g1 = sWs + (hh * 32) * LW + l31;   // G1: + s*LW + 32t          (Ws[k][h], lanes over h)
+  const float* pW1_c = sW1 + l31 * LW + 4 * hh;       // G2: + 32t*LW + 32ht+ROWC  (W1[m][h], lanes over m)
+  const float* pW2_c = sW2 + l31 * LW + 4 * hh;       // G3: + 32t*LW + 32mt+ROWC  (W2[d][m], lanes over d)
+  const float* pW2_r = sW2 + (4 * hh) * LW + l31;     // G5: + (32dt+ROWC)*LW + 32t (lanes over m)
+  const float* pW1_r = sW1 + (4 * hh) * LW + l31;     // G6: + (32mt+ROWC)*LW + 32t (lanes over h)
+  const float* pWs_c = sWs + l31 * LW + 4 * hh;       // G7: + 32t*LW + 32ht+ROWC  (lanes over k)
+  const float* imA = bufA + hh * LDB + l31;           // image operand reads: + 2s*LDB + 32t
+  const float* imB = bufB + hh * LDB + l31;
+  float* wrA = bufA + l31 * LDB + 4 * hh;             // image stores: + 32t + 8q (16 bytes)
+  float* wrB = bufB + l31 * LDB + 4 * hh;
+  const float* pb1 = sb1 + 4 * hh;                    // + 32t + 8q
+  const float* pb2 = sb2 + 4 * hh;
+  const float* pis = sIsig + 4 * hh;
+  const float* pc2 = sC2 + 4 * hh;
+
+  f32x16 dW2a[2][2], dW1a[2][2], dWsa[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { dW2a[i][j] = (f32x16)(0.f); dW1a[i][j] = (f32x16)(0.f); dWsa[i][j] = (f32x16)(0.f); }
+  float cs_gmu = 0.f, cs_gmu2 = 0.f, cs_da1 = 0.f;
+
+  const int64_t ntiles = (a.N + 31) / 32;
+  const int64_t tstride = 4 * (int64_t)nchunks;
+  int64_t tile = (int64_t)chunk * 4 + wave;
+  int64_t n = tile * 32 + l31;
+  bool live = n < a.N;
+  f32x4 zreg[8], xreg[2][4];
+  auto load_z = [&](int64_t nn, bool lv) {
+    const f32x4* zp = reinterpret_cast<const f32x4*>(a.z + (lv ? nn : 0) * K + hh * 32);
+#pragma unroll
+    for (int v = 0; v < 8; ++v) zreg[v] = lv ? zp[v] : (f32x4)(0.f);
+  };
+  auto load_x = [&](int64_t nn, bool lv) {
+    int64_t xr = lv ? nn : 0;
+    if (xr >= a.B) xr %= a.B;
+    const float* xp = a.X + xr * (int64_t)a.D + (int64_t)g * DG + 4 * hh;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xreg[dt][q] = *reinterpret_cast<const f32x4*>(xp + 32 * dt + 8 * q);
+  };
+  if (tile < ntiles) { load_z(n, live); load_x(n, live); }
+  auto none = [](int) {};
+
+  for (; tile < ntiles; tile += tstride) {
+    const int64_t n_next = (tile + tstride) * 32 + l31;
+    const bool has_next = (tile + tstride) < ntiles;
+    const bool live_next = has_next && (n_next < a.N);
+    const float livef = live ? 1.0f : 0.0f;
+    f32x16 hacc[2], tacc[2], gacc[2], dacc[2], eacc[2], zacc[2];
+    f32x4 cA, cB, cC;  // per-quad constants of the element-wise chunks
+
+    // ---- P1  G1: h^T = Ws^T z^T (two tiles share z) ----
+    phase2w<32, true>(hacc[0], hacc[1],
+        [&](int s, int t) { return pWs_g1[s * LW + 32 * t]; },
+        [&](int s) { return zreg[s >> 2][s & 3]; }, none);
+    // ---- P2  G2: a1^T = W1 h^T, tile by tile; tanh of tile 0 under tile 1 ----
+    auto w_g2 = [&](int t) { return [=](int s) { return pW1_c[32 * t * LW + 32 * (s >> 4) + OIVAE_ROWC(s & 15)]; }; };
+    auto b_h = [&](int s) { return hacc[s >> 4][s & 15]; };
+    auto tanh_chunk = [&](int t, int e) {  // element e (0..15) of tile t: add bias, tanh
+      if ((e & 3) == 0) cA = *reinterpret_cast<const f32x4*>(pb1 + 32 * t + 8 * (e >> 2));
+      tacc[t][e] = fast_tanh(tacc[t][e] + cA[e & 3]);
+    };
+    phase1<32, true>(tacc[0], w_g2(0), b_h, none);
+    phase1<32, true>(tacc[1], w_g2(1), b_h, [&](int s) { if (!(s & 1)) tanh_chunk(0, s >> 1); });
+    // ---- P3  G3: mu^T = W2 t^T.  k-steps over t tile 0 first (tanh of tile 1 under them) ----
+    phase2w<16, true>(gacc[0], gacc[1],
+        [&](int s, int t) { return pW2_c[32 * t * LW + OIVAE_ROWC(s)]; },
+        [&](int s) { return tacc[0][s]; },
+        [&](int u) { if (!(u & 1)) tanh_chunk(1, u >> 1); });
+    auto img_store = [&](float* base, const f32x16& v, int t, int q) {
+      f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+      *reinterpret_cast<f32x4*>(base + 32 * t + 8 * q) = o;
+    };
+    phase1<16, false>(gacc[0], [&](int s) { return pW2_c[32 + OIVAE_ROWC(s)]; },
+                      [&](int s) { return tacc[1][s]; },
+                      [&](int s) { if (s < 8) img_store(wrB, tacc[s >> 2], s >> 2, s & 3); });  // t image -> bufB
+    auto epi_chunk = [&](int t, int e) {  // residual -> dL/dmu for element e of tile t
+      if ((e & 3) == 0) {
+        cA = *reinterpret_cast<const f32x4*>(pb2 + 32 * t + 8 * (e >> 2));
+        cB = *reinterpret_cast<const f32x4*>(pis + 32 * t + 8 * (e >> 2));
+        cC = *reinterpret_cast<const f32x4*>(pc2 + 32 * t + 8 * (e >> 2));
+      }
+      const float qv = (xreg[t][e >> 2][e & 3] - (gacc[t][e] + cA[e & 3])) * cB[e & 3];
+      gacc[t][e] = -(qv * cC[e & 3]) * livef;
+      if ((e & 3) == 3) img_store(wrA, gacc[t], t, e >> 2);  // gmu image -> bufA
+    };
+    phase1<16, false>(gacc[1], [&](int s) { return pW2_c[32 * LW + 32 + OIVAE_ROWC(s)]; },
+                      [&](int s) { return tacc[1][s]; },
+                      [&](int s) { epi_chunk(0, s); });
+    // ---- P4  W1: dW2 += gmu^T t.  rows i=0 first; epilogue of tile 1 and the x prefetch under them ----
+    auto imrow = [&](const float* im, int col) { return [=](int s) { return im[2 * s * LDB + col]; }; };
+    phasewg<16>(dW2a[0][0], dW2a[0][1], imrow(imA, 0), imrow(imA, 0), imrow(imB, 0), imrow(imB, 32),
+                [&](int u) { if (!(u & 1)) epi_chunk(1, u >> 1); });
+    if (has_next) load_x(n_next, live_next);
+    float s1 = 0.f, s2 = 0.f;
+    phasewg<16>(dW2a[1][0], dW2a[1][1], imrow(imA, 32), imrow(imA, 32), imrow(imB, 0), imrow(imB, 32),
+                [&](int u) { const float v = bufA[u * LDB + lane]; s1 += v; s2 = fmaf(v, v, s2); });
+    cs_gmu += s1; cs_gmu2 += s2;
+    // ---- P5  G5: dt^T = W2^T gmu^T tile by tile; da1 of tile 0 and the images under tile 1 ----
+    auto w_g5 = [&](int t) { return [=](int s) { return pW2_r[(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * LW + 32 * t]; }; };
+    auto b_g = [&](int s) { return gacc[s >> 4][s & 15]; };
+    phase1<32, true>(dacc[0], w_g5(0), b_g, none);
+    phase1<32, true>(dacc[1], w_g5(1), b_g, [&](int s) {
+      if (s < 16) {
+        dacc[0][s] = dacc[0][s] * (1.0f - tacc[0][s] * tacc[0][s]);
+        if ((s & 3) == 3) img_store(wrA, dacc[0], 0, s >> 2);      // da1 tile 0 -> bufA
+      } else if (s < 24) {
+        img_store(wrB, hacc[(s - 16) >> 2], (s - 16) >> 2, (s - 16) & 3);  // h image -> bufB
+      }
+    });
+    // ---- P6  W2: dW1 += da1^T h ----
+    phasewg<16>(dW1a[0][0], dW1a[0][1], imrow(imA, 0), imrow(imA, 0), imrow(imB, 0), imrow(imB, 32),
+                [&](int u) {
+                  if (!(u & 1)) {
+                    const int e = u >> 1;
+                    dacc[1][e] = dacc[1][e] * (1.0f - tacc[1][e] * tacc[1][e]);
+                    if ((e & 3) == 3) img_store(wrA, dacc[1], 1, e >> 2);
+                  }
+                });
+    float s3 = 0.f;
+    phasewg<16>(dW1a[1][0], dW1a[1][1], imrow(imA, 32), imrow(imA, 32), imrow(imB, 0), imrow(imB, 32),
+                [&](int u) { s3 += bufA[u * LDB + lane]; });
+    cs_da1 += s3;
+    // ---- P7  G6: dh^T = W1^T da1^T tile by tile; dh/z images and the z prefetch under tile 1 ----
+    auto w_g6 = [&](int t) { return [=](int s) { return pW1_r[(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * LW + 32 * t]; }; };
+    auto b_d = [&](int s) { return dacc[s >> 4][s & 15]; };
+    phase1<32, true>(eacc[0], w_g6(0), b_d, none);
+    phase1<32, true>(eacc[1], w_g6(1), b_d, [&](int s) {
+      if (s < 4) img_store(wrB, eacc[0], 0, s);                                    // dh tile 0 -> bufB
+      else if (s < 12) *reinterpret_cast<f32x4*>(bufA + l31 * LDB + hh * 32 + 4 * (s - 4)) = zreg[s - 4];  // z -> bufA
+    });
+    if (has_next) load_z(n_next, live_next);
+    // ---- P8  W3: dWs += z^T dh.  columns j=0 first; dh tile 1 image under them ----
+    phasewg<16>(dWsa[0][0], dWsa[1][0], imrow(imA, 0), imrow(imA, 32), imrow(imB, 0), imrow(imB, 0),
+                [&](int u) { if (u < 4) img_store(wrB, eacc[1], 1, u); });
+    phasewg<16>(dWsa[0][1], dWsa[1][1], imrow(imA, 0), imrow(imA, 32), imrow(imB, 32), imrow(imB, 32), none);
+    // ---- P9  G7: dz^T = Ws dh^T tile by tile; atomics of tile 0 under tile 1 ----
+    auto w_g7 = [&](int t) { return [=](int s) { return pWs_c[32 * t * LW + 32 * (s >> 4) + OIVAE_ROWC(s & 15)]; }; };
+    auto b_e = [&](int s) { return eacc[s >> 4][s & 15]; };
+    float* dzp = a.dzT + (int64_t)(4 * hh) * a.N + (live ? n : 0);
+    phase1<32, true>(zacc[0], w_g7(0), b_e, none);
+    phase1<32, true>(zacc[1], w_g7(1), b_e, [&](int s) {
+      if (!(s & 1) && live) atomicAdd(dzp + (int64_t)OIVAE_ROWC(s >> 1) * a.N, zacc[0][s >> 1]);
+    });
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) atomicAdd(dzp + (int64_t)(32 + OIVAE_ROWC(r)) * a.N, zacc[1][r]);
+    }
+    n = n_next;
+    live = live_next;
+  }
+
+  // ---- reduce the four waves' partials in a fixed order and store (as v1) ----
+  const int64_t cs = a.chunk_stride * chunk;
+  float* stage = sAct;
+  auto reduce_store = [&](f32x16 (&acc)[2][2], float* dst) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stage[wave * 4096 + (32 * i + OIVAE_ROW(r, hh)) * 64 + 32 * j + l31] = acc[i][j][r];
+    __syncthreads();
+    for (int idx = tid; idx < 4096; idx += 256) {
+      float s = stage[idx];
+      s += stage[4096 + idx];
+      s += stage[2 * 4096 + idx];
+      s += stage[3 * 4096 + idx];
+      dst[idx] = s;
+    }
+  };
+  reduce_store(dW2a, a.gW2 + cs + (int64_t)g * DG * M);
+  reduce_store(dW1a, a.gW1 + cs + (int64_t)g * M * H);
+  reduce_store(dWsa, a.gWs + cs + (int64_t)g * K * H);
+  __syncthreads();
+  stage[wave * 192 + lane] = cs_gmu;
+  stage[wave * 192 + 64 + lane] = cs_gmu2;
+  stage[wave * 192 + 128 + lane] = cs_da1;
+  __syncthreads();
+  float* sred = stage + 1024;
+  if (tid < 64) {
+    const float s_gmu = ((stage[tid] + stage[192 + tid]) + stage[384 + tid]) + stage[576 + tid];
+    const float s_gmu2 = ((stage[64 + tid] + stage[256 + tid]) + stage[448 + tid]) + stage[640 + tid];
+    const float s_da1 = ((stage[128 + tid] + stage[320 + tid]) + stage[512 + tid]) + stage[704 + tid];
+    const int64_t d = (int64_t)g * DG + tid;
+    const float e = expf(a.ls[d]);
+    const float sg = e + a.sig_off;
+    const float c2 = a.inv / sg;
+    const float sumq2 = s_gmu2 / (c2 * c2);
+    const float nrows = (chunk == 0) ? (float)a.N : 0.f;
+    a.gb2[cs + d] = s_gmu;
+    a.gls[cs + d] = (nrows - sumq2) * (e * a.inv / sg);
+    a.gb1[cs + (int64_t)g * M + tid] = s_da1;
+    sred[tid] = nrows * (-0.5f * kLog2Pi - logf(sg)) - 0.5f * sumq2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < 64; ++i) tot += (double)sred[i];
+    a.ll_part[(int64_t)chunk * gridDim.x + g] = tot;
+  }
+}
+
 bool mfma_decoder_applies(const oivae_shape_t& s) {
   if (getenv("OIVAE_FORCE_GENERIC")) return false;  // test hook: cross-check the two kernel families
   if (s.gen_type != OIVAE_GEN_MLP) return false;
@@ -479,7 +792,14 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   a.sig_off = gen_sig_off;
   a.ll_part = w.ll_part;
   int rc;
-  if (s.K == 64) rc = launch_one<64, 64, 64, 64>(a, s.G, chunks, st);
+  if (s.K == 64 && !getenv("OIVAE_DEC_V1")) {
+    const size_t lds = (size_t)(3 * 64 * 65 + 64 + 3 * 64 + 4 * 2 * 32 * 68) * sizeof(float);
+    OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_mfma64_v2),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(dec_mfma64_v2, dim3((unsigned)s.G, (unsigned)chunks), dim3(256), lds, st, a);
+    OIVAE_LAUNCH_CHECK();
+    rc = OIVAE_OK;
+  } else if (s.K == 64) rc = launch_one<64, 64, 64, 64>(a, s.G, chunks, st);
   else rc = launch_one<32, 32, 32, 32>(a, s.G, chunks, st);
   if (rc) return rc;
   if (chunks > 1) {

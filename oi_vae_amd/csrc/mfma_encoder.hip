@@ -32,7 +32,7 @@ template <int WM, int WN, int WGM, int WGN>
 __global__ __launch_bounds__(256) void enc_fwd_gemm(const float* __restrict__ X, int64_t B, int D, int K,
                                                     const float* __restrict__ Wmu,
                                                     const float* __restrict__ Wsig,
-                                                    float* __restrict__ pre) {
+                                                    float* __restrict__ pre, int klen) {
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN, LD = 36;
   constexpr int A4 = BM * 8 / 256, B4 = BN * 8 / 256;  // float4 loads per thread per tile
@@ -89,12 +89,16 @@ __global__ __launch_bounds__(256) void enc_fwd_gemm(const float* __restrict__ X,
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[i][j] = (f32x16)(0.f);
 
-  const int T = D / 32;
-  gload(0);
+  // split-K: blockIdx.z owns columns [kbeg, kend) of X and writes its own partial image of pre
+  const int kbeg = blockIdx.z * klen;
+  const int kend = (kbeg + klen < D) ? kbeg + klen : D;
+  const int T = (kend - kbeg) / 32;
+  pre += (int64_t)blockIdx.z * B * J;
+  gload(kbeg);
   lstore(0);
   __syncthreads();
   for (int t = 0; t < T; ++t) {
-    if (t + 1 < T) gload((t + 1) * 32);
+    if (t + 1 < T) gload(kbeg + (t + 1) * 32);
     const float* a = sA + (t & 1) * BM * LD + (wm * WM * 32 + l31) * LD + 4 * hh;
     const float* b = sB + (t & 1) * BN * LD + (wn * WN * 32 + l31) * LD + 4 * hh;
 #pragma unroll
@@ -231,15 +235,42 @@ bool mfma_encoder_applies(const oivae_shape_t& s) {
   return (s.D % 32 == 0) && ((2 * s.K) % 32 == 0);
 }
 
+// tile shape (rows x cols of pre per workgroup) and K-splits for a given problem: big batches use
+// 256-row tiles (X read once, weights re-read B/256 times from L2); small batches (data-parallel
+// shards) use 64-row tiles and split the reduction over D so that >= 256 workgroups exist.
+struct FwdPlan { int cfg; int splits; };
+static FwdPlan plan_fwd(const oivae_shape_t& s, int64_t B) {
+  const int J = 2 * s.K;
+  FwdPlan p;
+  const bool big = B >= 256 * 192;
+  int bm, bn;
+  if (J % 128 == 0) { p.cfg = big ? 0 : 1; bm = big ? 256 : 64; bn = 128; }
+  else if (J % 64 == 0) { p.cfg = big ? 2 : 3; bm = big ? 256 : 64; bn = 64; }
+  else { p.cfg = 4; bm = 128; bn = 32; }
+  const int64_t tiles = ((B + bm - 1) / bm) * ((J + bn - 1) / bn);
+  int splits = 1;
+  const int ktiles = s.D / 32;
+  while (splits < kMaxEncSplits && tiles * splits < 256 && ktiles / (splits * 2) >= 16) splits *= 2;
+  p.splits = splits;
+  return p;
+}
+
+int mfma_encoder_fwd_splits(const oivae_shape_t& s, int64_t B) {
+  if (!mfma_encoder_applies(s)) return 1;
+  return plan_fwd(s, B).splits;
+}
+
 template <int WM, int WN, int WGM, int WGN>
 static int launch_fwd(const float* X, int64_t B, int D, int K, const float* Wmu, const float* Wsig, float* pre,
-                      hipStream_t st) {
+                      int splits, hipStream_t st) {
   constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
   const size_t lds = sizeof(float) * 2 * (BM + BN) * 36;
   OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_fwd_gemm<WM, WN, WGM, WGN>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const dim3 grid((unsigned)((B + BM - 1) / BM), (unsigned)((2 * K + BN - 1) / BN));
-  hipLaunchKernelGGL((enc_fwd_gemm<WM, WN, WGM, WGN>), grid, dim3(256), lds, st, X, B, D, K, Wmu, Wsig, pre);
+  const int ktiles = D / 32;
+  const int klen = ((ktiles + splits - 1) / splits) * 32;
+  const dim3 grid((unsigned)((B + BM - 1) / BM), (unsigned)((2 * K + BN - 1) / BN), (unsigned)splits);
+  hipLaunchKernelGGL((enc_fwd_gemm<WM, WN, WGM, WGN>), grid, dim3(256), lds, st, X, B, D, K, Wmu, Wsig, pre, klen);
   OIVAE_LAUNCH_CHECK();
   return OIVAE_OK;
 }
@@ -249,17 +280,15 @@ int launch_encoder_fwd_mfma(const oivae_shape_t& s, const oivae_tensors_t* param
   if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(params->enc_Wmu) & 15) ||
       (reinterpret_cast<uintptr_t>(params->enc_Wsig) & 15))
     return fail(OIVAE_E_ARG, "MFMA encoder: X, Wmu, Wsig must be 16-byte aligned");
-  const int J = 2 * s.K;
-  const bool big = B >= 256 * 192;  // enough 256-row tiles to fill the chip
-  if (J % 128 == 0) {
-    if (big) return launch_fwd<2, 4, 4, 1>(X, B, s.D, s.K, params->enc_Wmu, params->enc_Wsig, pre, st);
-    return launch_fwd<1, 2, 2, 2>(X, B, s.D, s.K, params->enc_Wmu, params->enc_Wsig, pre, st);
+  const FwdPlan p = plan_fwd(s, B);
+  const float *Wm = params->enc_Wmu, *Wg = params->enc_Wsig;
+  switch (p.cfg) {
+    case 0: return launch_fwd<2, 4, 4, 1>(X, B, s.D, s.K, Wm, Wg, pre, p.splits, st);
+    case 1: return launch_fwd<1, 2, 2, 2>(X, B, s.D, s.K, Wm, Wg, pre, p.splits, st);
+    case 2: return launch_fwd<2, 2, 4, 1>(X, B, s.D, s.K, Wm, Wg, pre, p.splits, st);
+    case 3: return launch_fwd<1, 1, 2, 2>(X, B, s.D, s.K, Wm, Wg, pre, p.splits, st);
+    default: return launch_fwd<1, 1, 4, 1>(X, B, s.D, s.K, Wm, Wg, pre, p.splits, st);
   }
-  if (J % 64 == 0) {
-    if (big) return launch_fwd<2, 2, 4, 1>(X, B, s.D, s.K, params->enc_Wmu, params->enc_Wsig, pre, st);
-    return launch_fwd<1, 1, 2, 2>(X, B, s.D, s.K, params->enc_Wmu, params->enc_Wsig, pre, st);
-  }
-  return launch_fwd<1, 1, 4, 1>(X, B, s.D, s.K, params->enc_Wmu, params->enc_Wsig, pre, st);
 }
 
 template <int TJ>
