@@ -107,7 +107,7 @@ def prox_roofline(device):
           "zeroed_fraction": float(mask.float().mean())}
 
 
-def cpu_baseline(batch=1024, steps=2):
+def cpu_baseline(batch=1024, steps=8):
   """The oracle (CPU restatement with the reference's per-group loop) on the host
   cores, same shapes at a reduced batch; reported, not a target."""
   import numpy as np
