@@ -757,6 +757,9 @@ __global__ __launch_bounds__(256) void dec_mfma64_v2(MfmaDecArgs a) {
 //   * z gets an LDS image of its own, written at the start of the tile, which frees its
 //     registers for the prefetch after the first product.
 // ==============================================================================
+// ABL != 0 exists only in diagnostic builds (-DOIVAE_DIAG_VARIANTS, tools/dec_ablate.sh): each bit drops one class of
+// non-MFMA work so that its un-hidden cost can be timed; the results of such a launch are meaningless.
+template <int ABL>
 __global__ __launch_bounds__(256) void dec_mfma64_v3(MfmaDecArgs a) {
   constexpr int K = 64, H = 64, M = 64, DG = 64;
   constexpr int LW = 65, LDB = 68;
@@ -873,6 +876,7 @@ __global__ __launch_bounds__(256) void dec_mfma64_v3(MfmaDecArgs a) {
     f32x4 cA, cB;
 
     auto img_store = [&](float* base, const f32x16& v, int t, int q) {
+      if (ABL & 8) return;
       f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
       *reinterpret_cast<f32x4*>(base + 32 * t + 8 * q) = o;
     };
@@ -883,11 +887,12 @@ __global__ __launch_bounds__(256) void dec_mfma64_v3(MfmaDecArgs a) {
     auto b_z = [&](int s) { return zreg[s >> 2][s & 3]; };
     auto tanh_chunk = [&](int t, int e) {
       if ((e & 3) == 0) cA = *reinterpret_cast<const f32x4*>(pb1 + 32 * t + 8 * (e >> 2));
-      tacc[t][e] = fast_tanh(tacc[t][e] + cA[e & 3]);
+      if (ABL & 2) tacc[t][e] = tacc[t][e] + cA[e & 3];
+      else tacc[t][e] = fast_tanh(tacc[t][e] + cA[e & 3]);
     };
     phase1<32, true>(tacc[0], w_p1(0), b_z, [&](int s) {
-      atomicAdd(dzp_prev + (int64_t)(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * a.N, zacc[s >> 4][s & 15]);
-      if ((s & 3) == 3) *reinterpret_cast<f32x4*>(wrZ + 4 * (s >> 2)) = zreg[s >> 2];
+      if (!(ABL & 1)) atomicAdd(dzp_prev + (int64_t)(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * a.N, zacc[s >> 4][s & 15]);
+      if (!(ABL & 8)) if ((s & 3) == 3) *reinterpret_cast<f32x4*>(wrZ + 4 * (s >> 2)) = zreg[s >> 2];
     });
     phase1<32, true>(tacc[1], w_p1(1), b_z, [&](int s) { if ((s & 1) && s < 32) tanh_chunk(0, s >> 1); });
     // ---- P3  mu^T = W2 t^T.  k over t tile 0 first (tanh of tile 1 under it) ----
@@ -903,7 +908,8 @@ __global__ __launch_bounds__(256) void dec_mfma64_v3(MfmaDecArgs a) {
         cA = *reinterpret_cast<const f32x4*>(pb2 + 32 * t + 8 * (e >> 2));
         cB = *reinterpret_cast<const f32x4*>(pc3 + 32 * t + 8 * (e >> 2));
       }
-      gacc[t][e] = ((gacc[t][e] + cA[e & 3]) - xreg[t][e >> 2][e & 3]) * (cB[e & 3] * livef);
+      if (ABL & 16) gacc[t][e] = gacc[t][e] * livef;
+      else gacc[t][e] = ((gacc[t][e] + cA[e & 3]) - xreg[t][e >> 2][e & 3]) * (cB[e & 3] * livef);
       if ((e & 3) == 3) img_store(wrA, gacc[t], t, e >> 2);  // gmu image
     };
     phase1<16, false>(gacc[1], [&](int s) { return pW2_c[32 * LW + 32 + OIVAE_ROWC(s)]; },
@@ -913,20 +919,20 @@ __global__ __launch_bounds__(256) void dec_mfma64_v3(MfmaDecArgs a) {
     phasewg<16>(dW2a[0][0], dW2a[0][1], imrow(imA, 0), imrow(imA, 0), imrow(imB, 0), imrow(imB, 32),
                 [&](int u) {
                   if (u >= 2 && u < 18) epi_chunk(1, u - 2);
-                  else if (u >= 18 && u < 26) zreg[u - 18] = zp_next[u - 18];
+                  else if (!(ABL & 32) && u >= 18 && u < 26) zreg[u - 18] = zp_next[u - 18];
                 });
     float s1 = 0.f, s2 = 0.f;
     phasewg<16>(dW2a[1][0], dW2a[1][1], imrow(imA, 32), imrow(imA, 32), imrow(imB, 0), imrow(imB, 32),
-                [&](int u) { const float v = bufA[u * LDB + lane]; s1 += v; s2 = fmaf(v, v, s2); });
+                [&](int u) { if (!(ABL & 4)) { const float v = bufA[u * LDB + lane]; s1 += v; s2 = fmaf(v, v, s2); } });
     cs_gmu += s1; cs_gmu2 += s2;
     // ---- P5  dt^T = W2^T gmu^T tile by tile; x prefetch under tile 0, da1 of tile 0 under tile 1 ----
     auto w_p5 = [&](int t) { return [=](int s) { return pW2_r[(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * LW + 32 * t]; }; };
     auto b_g = [&](int s) { return gacc[s >> 4][s & 15]; };
     phase1<32, true>(dacc[0], w_p5(0), b_g, [&](int s) {
-      if (s >= 2 && s < 10) xreg[(s - 2) >> 2][(s - 2) & 3] = *reinterpret_cast<const f32x4*>(xp_next + 32 * ((s - 2) >> 2) + 8 * ((s - 2) & 3));
+      if (!(ABL & 32) && s >= 2 && s < 10) xreg[(s - 2) >> 2][(s - 2) & 3] = *reinterpret_cast<const f32x4*>(xp_next + 32 * ((s - 2) >> 2) + 8 * ((s - 2) & 3));
     });
     auto da1_chunk = [&](int t, int e) {
-      dacc[t][e] = dacc[t][e] * (1.0f - tacc[t][e] * tacc[t][e]);
+      if (!(ABL & 64)) dacc[t][e] = dacc[t][e] * (1.0f - tacc[t][e] * tacc[t][e]);
       if ((e & 3) == 3) img_store(wrA, dacc[t], t, e >> 2);
     };
     phase1<32, true>(dacc[1], w_p5(1), b_g, [&](int s) { if (s >= 1 && s < 17) da1_chunk(0, s - 1); });
@@ -935,7 +941,7 @@ __global__ __launch_bounds__(256) void dec_mfma64_v3(MfmaDecArgs a) {
                 [&](int u) { if (u >= 2 && u < 18) da1_chunk(1, u - 2); });
     float s3 = 0.f;
     phasewg<16>(Pa[1][0], Pa[1][1], imrow(imA, 32), imrow(imA, 32), imrow(imZ, 0), imrow(imZ, 32),
-                [&](int u) { s3 += bufA[u * LDB + lane]; });
+                [&](int u) { if (!(ABL & 4)) s3 += bufA[u * LDB + lane]; });
     cs_da1 += s3;
     // ---- P7  dz^T = A^T da1^T tile by tile (atomics deferred to the next row tile) ----
     auto w_p7 = [&](int t) { return [=](int s) { return pA_c[(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * LW + 32 * t]; }; };
@@ -946,7 +952,7 @@ __global__ __launch_bounds__(256) void dec_mfma64_v3(MfmaDecArgs a) {
     n = n_next;
     live = live_next;
   }
-  if (had_tiles) {
+  if (had_tiles && !(ABL & 1)) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1034,6 +1040,391 @@ __global__ __launch_bounds__(256) void dec_mfma64_v3(MfmaDecArgs a) {
   }
 }
 
+
+// ==============================================================================
+// v4 of the all-64 kernel: v3's six-product data flow with the instruction stream
+// rebuilt around one measured fact (tools/probe/mfma_probe2.hip on MI355X): next to
+// v_mfma_f32_32x32x2_f32 every vector-ALU instruction of the same wave costs ~8
+// cycles of matrix time (a transcendental ~12), packed f32 forms cost the same as
+// scalar ones, while scalar ALU, s_waitcnt, s_nop and LDS reads cost ~0-2.  fp32
+// "matrix" work shares the vector ALU, so the lever is the NUMBER of VALU
+// instructions per tile (v3: 910, of which 256 were AGPR<->VGPR copies):
+//   * accumulators that element-wise code touches (a1/t, mu/gmu, dt/da1, dz) use the
+//     VGPR form of the MFMA (inline asm: the compiler only emits the AGPR form in a
+//     512-register kernel), so no v_accvgpr copies; the two weight-gradient
+//     accumulators stay in AGPRs through the builtin;
+//   * biases are folded into the accumulator's initial value (loaded from LDS),
+//     the tanh argument scale 2*log2(e) into a second copy of A;
+//   * all element-wise math is written on register pairs (v_pk_*_f32);
+//   * column sums are accumulated as pairs and folded once at the end;
+//   * tile bookkeeping and the atomics' row bases are scalar (wave index through
+//     readfirstlane, 32-bit per-lane offsets).
+// Hazards of the asm MFMAs (the compiler does not pad inline asm): every asm MFMA is
+// preceded by s_nop 1 (VALU-written operand -> MFMA), and every consumer of an asm
+// MFMA's result is placed at least two 64-cycle MFMAs later in program order,
+// pinned by sched_barrier(0) after every slot.
+// ==============================================================================
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+__device__ __forceinline__ void mfv(f32x16& acc, float a_, float b_) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a_), "v"(b_));
+}
+__device__ __forceinline__ void mfv0(f32x16& acc, float a_, float b_) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(a_), "v"(b_));
+}
+
+// one output tile held in VGPRs, NK k-steps
+template <int NK, bool FRESH, class WF, class BF, class VF>
+__device__ __forceinline__ void vphase1(f32x16& acc, WF wf, BF bf, VF vf) {
+  float w[NK];
+  w[0] = wf(0); w[1] = wf(1); w[2] = wf(2);
+#pragma unroll
+  for (int s = 0; s < NK; ++s) {
+    if (s + 3 < NK) w[s + 3] = wf(s + 3);
+    vf(s);
+    if (FRESH && s == 0) mfv0(acc, w[s], bf(s)); else mfv(acc, w[s], bf(s));
+    OIVAE_SB();
+  }
+}
+
+// two VGPR output tiles sharing the register operand (accumulating in place); MFMA slot u = 2s+t
+template <int NK, class WF, class BF, class VF>
+__device__ __forceinline__ void vphase2w(f32x16& acc0, f32x16& acc1, WF wf, BF bf, VF vf) {
+  float w[NK][2];
+  w[0][0] = wf(0, 0); w[0][1] = wf(0, 1); w[1][0] = wf(1, 0); w[1][1] = wf(1, 1);
+#pragma unroll
+  for (int s = 0; s < NK; ++s) {
+    if (s + 2 < NK) { w[s + 2][0] = wf(s + 2, 0); w[s + 2][1] = wf(s + 2, 1); }
+    const float b = bf(s);
+    vf(2 * s);
+    mfv(acc0, w[s][0], b);
+    vf(2 * s + 1);
+    mfv(acc1, w[s][1], b);
+    OIVAE_SB();
+  }
+}
+
+__global__ __launch_bounds__(256) void dec_mfma64_v4(MfmaDecArgs a) {
+  constexpr int K = 64, H = 64, M = 64, DG = 64;
+  constexpr int LW = 65, LDB = 68;
+  constexpr float kC = 2.885390081777927f;  // 2*log2(e): tanh(x) = 1 - 2/(exp2(kC x) + 1)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sAf = reinterpret_cast<float*>(smem_raw);  // kC * A[m][k]   (forward)
+  float* sAb = sAf + M * LW;                         // A[m][k]        (backward)
+  float* sW2 = sAb + M * LW;
+  float* sb1 = sW2 + DG * LW;  // kC * b1
+  float* sb2 = sb1 + M;
+  float* sC3 = sb2 + DG;       // inv / sigma_d^2
+  float* sPad = sC3 + DG;
+  float* sAct = sPad + 64;     // 4 waves x 3 images x [32][LDB]
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int g = blockIdx.x, chunk = blockIdx.y, nchunks = gridDim.y;
+  const float* Wsg = a.Ws + (int64_t)g * K * H;
+  const float* W1g = a.W1 + (int64_t)g * M * H;
+  float* tW1 = sAct;
+  float* tWs = sAct + 64 * LW;
+  {
+    const float* W2g = a.W2 + (int64_t)g * DG * M;
+    for (int i = tid; i < 4096; i += 256) {
+      const int o = (i >> 6) * LW + (i & 63);
+      tW1[o] = W1g[i];
+      tWs[o] = Wsg[i];
+      sW2[o] = W2g[i];
+    }
+    if (tid < 64) {
+      const float sg = expf(a.ls[(int64_t)g * DG + tid]) + a.sig_off;
+      sb1[tid] = kC * a.b1[(int64_t)g * M + tid];
+      sb2[tid] = a.b2[(int64_t)g * DG + tid];
+      sC3[tid] = (a.inv / sg) / sg;
+    }
+  }
+  __syncthreads();
+  {
+    const int mt = wave >> 1, kt = wave & 1;
+    f32x16 acc = (f32x16)(0.f);
+    const float* pa = tW1 + (32 * mt + l31) * LW + hh;
+    const float* pb = tWs + (32 * kt + l31) * LW + hh;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) acc = mf32(pa[2 * s], pb[2 * s], acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = (32 * mt + OIVAE_ROW(r, hh)) * LW + 32 * kt + l31;
+      sAb[o] = acc[r];
+      sAf[o] = kC * acc[r];
+    }
+  }
+  __syncthreads();
+
+  float* bufA = sAct + wave * (3 * 32 * LDB);
+  float* bufB = bufA + 32 * LDB;
+  float* bufZ = bufB + 32 * LDB;
+  const float* pA_r = sAf + l31 * LW + 32 * hh;       // P1: + 32t*LW + s
+  const float* pW2_c = sW2 + l31 * LW + 4 * hh;       // P3: + 32t*LW + 32mt + ROWC
+  const float* pW2_r = sW2 + (4 * hh) * LW + l31;     // P5: + (32dt+ROWC)*LW + 32t
+  const float* pA_c = sAb + (4 * hh) * LW + l31;      // P7: + (32mt+ROWC)*LW + 32t
+  const float* imA = bufA + hh * LDB + l31;
+  const float* imB = bufB + hh * LDB + l31;
+  const float* imZ = bufZ + hh * LDB + l31;
+  float* wrA = bufA + l31 * LDB + 4 * hh;
+  float* wrB = bufB + l31 * LDB + 4 * hh;
+  float* wrZ = bufZ + l31 * LDB + 32 * hh;
+  const float* pb1 = sb1 + 4 * hh;
+  const float* pb2 = sb2 + 4 * hh;
+  const float* pc3 = sC3 + 4 * hh;
+  const float* csA = bufA + lane;                      // column sums: + row*LDB
+
+  f32x16 dW2a[2][2], Pa[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { dW2a[i][j] = (f32x16)(0.f); Pa[i][j] = (f32x16)(0.f); }
+  f32x2 s1p = {0.f, 0.f}, s2p = {0.f, 0.f}, s3p = {0.f, 0.f};  // pair accumulators of the column sums
+
+  const int N32 = (int)a.N;
+  const int ntiles = (N32 + 31) / 32;
+  const int tstride = 4 * nchunks;
+  int tile = chunk * 4 + wave;
+  const bool had_tiles = tile < ntiles;
+  const bool one_sample = (a.N == a.B);
+  f32x4 zreg[8], xreg[2][4];
+  f32x16 tacc[2], gacc[2], dacc[2], zacc[2];
+  zacc[0] = (f32x16)(0.f);
+  zacc[1] = (f32x16)(0.f);
+  auto row_of = [&](int t) { const int nn = t * 32 + l31; return nn < N32 ? nn : N32 - 1; };
+  auto z_ptr = [&](int nn) { return reinterpret_cast<const f32x4*>(a.z + (int64_t)nn * K + hh * 32); };
+  auto x_ptr = [&](int nn) {
+    const int64_t xr = one_sample ? (int64_t)nn : (int64_t)nn % a.B;
+    return a.X + xr * (int64_t)a.D + (int64_t)g * DG + 4 * hh;
+  };
+  auto load_bias = [&](f32x16& acc, const float* pb, int t) {  // accumulator := bias in accumulator layout
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pb + 32 * t + 8 * q);
+      acc[4 * q] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
+    }
+  };
+  int n = row_of(had_tiles ? tile : 0);
+  {
+    const f32x4* zp = z_ptr(n);
+#pragma unroll
+    for (int v = 0; v < 8; ++v) zreg[v] = zp[v];
+    const float* xp = x_ptr(n);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xreg[dt][q] = *reinterpret_cast<const f32x4*>(xp + 32 * dt + 8 * q);
+  }
+  load_bias(tacc[0], pb1, 0); load_bias(tacc[1], pb1, 1);
+  load_bias(gacc[0], pb2, 0); load_bias(gacc[1], pb2, 1);
+  // dz^T[k][n] lives at dzT + k*N + n: uniform row base (scalar) + 32-bit per-lane byte offset
+  char* const dzb = reinterpret_cast<char*>(a.dzT);
+  const int64_t rowbytes = a.N * 4;
+  uint32_t voff_prev = (uint32_t)((int64_t)(4 * hh) * a.N + n) * 4u;
+  auto none = [](int) {};
+
+  for (; tile < ntiles; tile += tstride) {
+    const int tnext = (tile + tstride < ntiles) ? tile + tstride : tile;
+    const int n_next = row_of(tnext);
+    const bool full = (tile * 32 + 32 <= N32);          // wave-uniform
+    const float livef = (tile * 32 + l31 < N32) ? 1.0f : 0.0f;
+    const f32x4* zp_next = z_ptr(n_next);
+    const float* xp_next = x_ptr(n_next);
+
+    auto img_store = [&](float* base, const f32x16& v, int t, int q) {
+      f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+      *reinterpret_cast<f32x4*>(base + 32 * t + 8 * q) = o;
+    };
+    auto imrow = [&](const float* im, int col) { return [=](int s) { return im[2 * s * LDB + col]; }; };
+    // t = 1 - 2/(exp2(arg)+1) on elements 2p, 2p+1 of an accumulator that holds kC*(a1+b1)
+    auto tanh_pair = [&](f32x16& acc, int p) {
+      f32x2 e = {__builtin_amdgcn_exp2f(acc[2 * p]), __builtin_amdgcn_exp2f(acc[2 * p + 1])};
+      e = e + 1.0f;
+      f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+      r = r * (-2.0f) + 1.0f;
+      acc[2 * p] = r[0]; acc[2 * p + 1] = r[1];
+    };
+    // gmu = (mu - x) * inv/sigma^2 on quad q (elements 4q..4q+3) of tile t, then its 16 bytes of the gmu image
+    auto epi_quad = [&](int t, int q) {
+      f32x4 c3 = *reinterpret_cast<const f32x4*>(pc3 + 32 * t + 8 * q);
+      if (!full) c3 = c3 * livef;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        f32x2 mu = {gacc[t][4 * q + 2 * h2], gacc[t][4 * q + 2 * h2 + 1]};
+        const f32x2 x = {xreg[t][q][2 * h2], xreg[t][q][2 * h2 + 1]};
+        const f32x2 c = {c3[2 * h2], c3[2 * h2 + 1]};
+        mu = (mu - x) * c;
+        gacc[t][4 * q + 2 * h2] = mu[0]; gacc[t][4 * q + 2 * h2 + 1] = mu[1];
+      }
+      img_store(wrA, gacc[t], t, q);
+    };
+    // da1 = dt * (1 - t^2) on quad q of tile t, then its 16 bytes of the da1 image
+    auto da1_quad = [&](int t, int q) {
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const f32x2 tt = {tacc[t][4 * q + 2 * h2], tacc[t][4 * q + 2 * h2 + 1]};
+        f32x2 d = {dacc[t][4 * q + 2 * h2], dacc[t][4 * q + 2 * h2 + 1]};
+        const f32x2 u = 1.0f - tt * tt;
+        d = d * u;
+        dacc[t][4 * q + 2 * h2] = d[0]; dacc[t][4 * q + 2 * h2 + 1] = d[1];
+      }
+      img_store(wrA, dacc[t], t, q);
+    };
+
+    // ---- P1  kC*(a1+b1)^T = (kC A) z^T + kC b1, tile by tile.  Under tile 0: dz atomics of the previous row tile, z image ----
+    auto w_p1 = [&](int t) { return [=](int s) { return pA_r[32 * t * LW + s]; }; };
+    auto b_z = [&](int s) { return zreg[s >> 2][s & 3]; };
+    vphase1<32, false>(tacc[0], w_p1(0), b_z, [&](int s) {
+      atomicAdd(reinterpret_cast<float*>(dzb + (int64_t)(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * rowbytes + voff_prev),
+                zacc[s >> 4][s & 15]);
+      if ((s & 3) == 3) *reinterpret_cast<f32x4*>(wrZ + 4 * (s >> 2)) = zreg[s >> 2];
+    });
+    vphase1<32, false>(tacc[1], w_p1(1), b_z, [&](int s) { if (s >= 2 && s < 10) tanh_pair(tacc[0], s - 2); });
+    // ---- P3  mu^T = W2 t^T + b2.  k over t tile 0 first (tanh of tile 1 under it) ----
+    vphase2w<16>(gacc[0], gacc[1],
+        [&](int s, int t) { return pW2_c[32 * t * LW + OIVAE_ROWC(s)]; },
+        [&](int s) { return tacc[0][s]; },
+        [&](int u) { if (u >= 2 && u < 10) tanh_pair(tacc[1], u - 2); });
+    vphase1<16, false>(gacc[0], [&](int s) { return pW2_c[32 + OIVAE_ROWC(s)]; },
+                       [&](int s) { return tacc[1][s]; },
+                       [&](int s) { if (s >= 2 && s < 10) img_store(wrB, tacc[(s - 2) >> 2], (s - 2) >> 2, (s - 2) & 3); });  // t image
+    vphase1<16, false>(gacc[1], [&](int s) { return pW2_c[32 * LW + 32 + OIVAE_ROWC(s)]; },
+                       [&](int s) { return tacc[1][s]; },
+                       [&](int s) { if (s >= 2 && s < 6) epi_quad(0, s - 2); });
+    // ---- P4  dW2 += gmu^T t.  rows i=0 first; epilogue of tile 1 and the z prefetch under them ----
+    phasewg<16>(dW2a[0][0], dW2a[0][1], imrow(imA, 0), imrow(imA, 0), imrow(imB, 0), imrow(imB, 32),
+                [&](int u) {
+                  if (u >= 2 && u < 6) epi_quad(1, u - 2);
+                  else if (u >= 8 && u < 16) zreg[u - 8] = zp_next[u - 8];
+                });
+    phasewg<16>(dW2a[1][0], dW2a[1][1], imrow(imA, 32), imrow(imA, 32), imrow(imB, 0), imrow(imB, 32),
+                [&](int u) {
+                  if (!(u & 1)) {
+                    const f32x2 v = {csA[u * LDB], csA[(u + 1) * LDB]};
+                    s1p = s1p + v;
+                    s2p = v * v + s2p;
+                  }
+                });
+    // ---- P5  dt^T = W2^T gmu^T tile by tile; x prefetch under tile 0, da1 of tile 0 under tile 1 ----
+    auto w_p5 = [&](int t) { return [=](int s) { return pW2_r[(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * LW + 32 * t]; }; };
+    auto b_g = [&](int s) { return gacc[s >> 4][s & 15]; };
+    vphase1<32, true>(dacc[0], w_p5(0), b_g, [&](int s) {
+      if (s >= 2 && s < 10) xreg[(s - 2) >> 2][(s - 2) & 3] = *reinterpret_cast<const f32x4*>(xp_next + 32 * ((s - 2) >> 2) + 8 * ((s - 2) & 3));
+    });
+    vphase1<32, true>(dacc[1], w_p5(1), b_g, [&](int s) { if (s >= 2 && s < 6) da1_quad(0, s - 2); });
+    // ---- P6  P += da1^T z.  rows m 0..31 first; da1 of tile 1 under them ----
+    phasewg<16>(Pa[0][0], Pa[0][1], imrow(imA, 0), imrow(imA, 0), imrow(imZ, 0), imrow(imZ, 32),
+                [&](int u) { if (u >= 2 && u < 6) da1_quad(1, u - 2); });
+    phasewg<16>(Pa[1][0], Pa[1][1], imrow(imA, 32), imrow(imA, 32), imrow(imZ, 0), imrow(imZ, 32),
+                [&](int u) {
+                  if (!(u & 1)) {
+                    const f32x2 v = {csA[u * LDB], csA[(u + 1) * LDB]};
+                    s3p = s3p + v;
+                  }
+                });
+    // ---- P7  dz^T = A^T da1^T tile by tile (atomics deferred); the next tile's bias images under them ----
+    auto w_p7 = [&](int t) { return [=](int s) { return pA_c[(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * LW + 32 * t]; }; };
+    auto b_d = [&](int s) { return dacc[s >> 4][s & 15]; };
+    voff_prev = (uint32_t)((int64_t)(4 * hh) * a.N + n) * 4u;
+    vphase1<32, true>(zacc[0], w_p7(0), b_d, [&](int s) {
+      if (s == 2) load_bias(gacc[0], pb2, 0);
+      if (s == 3) load_bias(gacc[1], pb2, 1);
+    });
+    vphase1<32, true>(zacc[1], w_p7(1), b_d, [&](int s) {
+      if (s == 2) load_bias(tacc[0], pb1, 0);
+      if (s == 3) load_bias(tacc[1], pb1, 1);
+    });
+    n = n_next;
+  }
+  if (had_tiles) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        atomicAdd(reinterpret_cast<float*>(dzb + (int64_t)(32 * t + OIVAE_ROWC(r)) * rowbytes + voff_prev), zacc[t][r]);
+  }
+  const float cs_gmu = s1p[0] + s1p[1], cs_gmu2 = s2p[0] + s2p[1], cs_da1 = s3p[0] + s3p[1];
+
+  // ---- reduce the four waves' partials in a fixed order (as v3) ----
+  const int64_t cs = a.chunk_stride * chunk;
+  float* stage = sAct;
+  auto stage_acc = [&](f32x16 (&acc)[2][2]) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stage[wave * 4096 + (32 * i + OIVAE_ROW(r, hh)) * 64 + 32 * j + l31] = acc[i][j][r];
+    __syncthreads();
+  };
+  stage_acc(dW2a);
+  {
+    float* dst = a.gW2 + cs + (int64_t)g * DG * M;
+    for (int idx = tid; idx < 4096; idx += 256)
+      dst[idx] = ((stage[idx] + stage[4096 + idx]) + stage[2 * 4096 + idx]) + stage[3 * 4096 + idx];
+  }
+  stage_acc(Pa);
+  float* sP = sAf;   // A's two copies and W2 are dead: P, W1 take their places
+  float* uW1 = sW2;
+  float* uWs = sAct + 4 * 4096;
+  for (int idx = tid; idx < 4096; idx += 256) {
+    const int o = (idx >> 6) * LW + (idx & 63);
+    sP[o] = ((stage[idx] + stage[4096 + idx]) + stage[2 * 4096 + idx]) + stage[3 * 4096 + idx];
+    uW1[o] = W1g[idx];
+    uWs[o] = Wsg[idx];
+  }
+  __syncthreads();
+  {
+    const int it = wave >> 1, ht = wave & 1;
+    f32x16 acc = (f32x16)(0.f);  // dW1[m][h] = sum_k P[m][k] Ws[k][h]
+    const float* pa = sP + (32 * it + l31) * LW + hh;
+    const float* pb = uWs + hh * LW + 32 * ht + l31;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) acc = mf32(pa[2 * s], pb[2 * s * LW], acc);
+    float* d1 = a.gW1 + cs + (int64_t)g * M * H;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d1[(32 * it + OIVAE_ROW(r, hh)) * H + 32 * ht + l31] = acc[r];
+    acc = (f32x16)(0.f);         // dWs[k][h] = sum_m P[m][k] W1[m][h]
+    pa = sP + hh * LW + 32 * it + l31;
+    pb = uW1 + hh * LW + 32 * ht + l31;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) acc = mf32(pa[2 * s * LW], pb[2 * s * LW], acc);
+    float* d2 = a.gWs + cs + (int64_t)g * K * H;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d2[(32 * it + OIVAE_ROW(r, hh)) * H + 32 * ht + l31] = acc[r];
+  }
+  stage[wave * 192 + lane] = cs_gmu;
+  stage[wave * 192 + 64 + lane] = cs_gmu2;
+  stage[wave * 192 + 128 + lane] = cs_da1;
+  __syncthreads();
+  float* sred = stage + 1024;
+  if (tid < 64) {
+    const float s_gmu = ((stage[tid] + stage[192 + tid]) + stage[384 + tid]) + stage[576 + tid];
+    const float s_gmu2 = ((stage[64 + tid] + stage[256 + tid]) + stage[448 + tid]) + stage[640 + tid];
+    const float s_da1 = ((stage[128 + tid] + stage[320 + tid]) + stage[512 + tid]) + stage[704 + tid];
+    const int64_t d = (int64_t)g * DG + tid;
+    const float e = expf(a.ls[d]);
+    const float sg = e + a.sig_off;
+    const float c2 = a.inv / sg;
+    const float sumq2 = s_gmu2 / (c2 * c2);
+    const float nrows = (chunk == 0) ? (float)a.N : 0.f;
+    a.gb2[cs + d] = s_gmu;
+    a.gls[cs + d] = (nrows - sumq2) * (e * a.inv / sg);
+    a.gb1[cs + (int64_t)g * M + tid] = s_da1;
+    sred[tid] = nrows * (-0.5f * kLog2Pi - logf(sg)) - 0.5f * sumq2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < 64; ++i) tot += (double)sred[i];
+    a.ll_part[(int64_t)chunk * gridDim.x + g] = tot;
+  }
+}
+
 bool mfma_decoder_applies(const oivae_shape_t& s) {
   if (getenv("OIVAE_FORCE_GENERIC")) return false;  // test hook: cross-check the two kernel families
   if (s.gen_type != OIVAE_GEN_MLP) return false;
@@ -1094,14 +1485,43 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   a.sig_off = gen_sig_off;
   a.ll_part = w.ll_part;
   int rc;
-  const char* ver = getenv("OIVAE_DEC");  // test hook: "v1" | "v2" select the older all-64 kernels
-  if (s.K == 64 && !ver) {
-    const size_t lds = (size_t)(2 * 64 * 65 + 4 * 64 + 4 * 3 * 32 * 68) * sizeof(float);
-    OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_mfma64_v3),
+  const char* ver = getenv("OIVAE_DEC");  // test hook: "v1" | "v2" | "v3" select the older all-64 kernels
+  if (s.K == 64 && !ver && N * (int64_t)s.K * 4 < (int64_t)1 << 32) {
+    const size_t lds = (size_t)(3 * 64 * 65 + 4 * 64 + 4 * 3 * 32 * 68) * sizeof(float);
+    OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_mfma64_v4),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(dec_mfma64_v3, dim3((unsigned)s.G, (unsigned)chunks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(dec_mfma64_v4, dim3((unsigned)s.G, (unsigned)chunks), dim3(256), lds, st, a);
     OIVAE_LAUNCH_CHECK();
     rc = OIVAE_OK;
+  } else if (s.K == 64 && (!ver || (ver[0] == 'v' && ver[1] == '3'))) {
+    const size_t lds = (size_t)(2 * 64 * 65 + 4 * 64 + 4 * 3 * 32 * 68) * sizeof(float);
+    rc = OIVAE_OK;
+#define OIVAE_V3_LAUNCH(ABL)                                                                             \
+  {                                                                                                      \
+    OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_mfma64_v3<ABL>),               \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+    hipLaunchKernelGGL(dec_mfma64_v3<ABL>, dim3((unsigned)s.G, (unsigned)chunks), dim3(256), lds, st, a); \
+  }
+#ifdef OIVAE_DIAG_VARIANTS
+    const char* ab = getenv("OIVAE_DEC_ABLATE");
+    const int abl = ab ? atoi(ab) : 0;
+    switch (abl) {
+      case 0: OIVAE_V3_LAUNCH(0) break;
+      case 1: OIVAE_V3_LAUNCH(1) break;
+      case 2: OIVAE_V3_LAUNCH(2) break;
+      case 4: OIVAE_V3_LAUNCH(4) break;
+      case 8: OIVAE_V3_LAUNCH(8) break;
+      case 16: OIVAE_V3_LAUNCH(16) break;
+      case 32: OIVAE_V3_LAUNCH(32) break;
+      case 64: OIVAE_V3_LAUNCH(64) break;
+      case 127: OIVAE_V3_LAUNCH(127) break;
+      default: return fail(OIVAE_E_ARG, "unknown OIVAE_DEC_ABLATE=%d", abl);
+    }
+#else
+    OIVAE_V3_LAUNCH(0)
+#endif
+#undef OIVAE_V3_LAUNCH
+    OIVAE_LAUNCH_CHECK();
   } else if (s.K == 64 && ver[0] == 'v' && ver[1] == '2') {
     const size_t lds = (size_t)(3 * 64 * 65 + 64 + 3 * 64 + 4 * 2 * 32 * 68) * sizeof(float);
     OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_mfma64_v2),
