@@ -220,10 +220,16 @@ class Engine:
 
   # ---- the step ----------------------------------------------------------------
   def forward_backward(self, X, eps, c, sig_off=1e-3, gen_sig_off=1e-3, prior_mu=None, prior_sigma=None,
-                       sigma_theta=1.0, lam=1.0):
+                       sigma_theta=1.0, lam=1.0, grad_sync=None):
     """Forward + backward of loss = z_kl - loglik_term - logprob_theta
     (/root/reference/lib/oivae.py:43-75).  Fills ``flat_grads`` completely and
-    returns mu_q, sig_q, z (fresh tensors) plus the 8-float scalar block."""
+    returns mu_q, sig_q, z (fresh tensors) plus the 8-float scalar block.
+
+    Kernel order: encoder forward, grouped decoder forward+backward, weight prior +
+    penalty + scalars (they need nothing from the encoder backward), encoder
+    backward.  ``grad_sync`` (parallel.BucketedGradSync) is told when the decoder's
+    and then the encoder's gradient segments are final, so that the data-parallel
+    all-reduce of the first overlaps the encoder backward."""
     s = self.spec
     with torch.cuda.device(self.device):
       X = self._dev_f32(X, "X")
@@ -260,14 +266,18 @@ class Engine:
       _lib.check(self._timed("decoder", lambda: L.oivae_decoder_fwd_bwd_f32(
         sh, pt, gt, X.data_ptr(), B, S, z.data_ptr(), float(gen_sig_off),
         dz.data_ptr(), ws.data_ptr(), self._ws_bytes, st)), "oivae_decoder_fwd_bwd_f32")
+      _lib.check(self._timed("finalize", lambda: L.oivae_finalize_f32(
+        sh, pt, gt, B, S, float(sigma_theta), float(lam), self.scalars.data_ptr(),
+        ws.data_ptr(), self._ws_bytes, st)), "oivae_finalize_f32")
+      if grad_sync is not None:
+        grad_sync.decoder_grads_ready()
       _lib.check(self._timed("encoder_bwd", lambda: L.oivae_encoder_bwd_f32(
         sh, gt, X.data_ptr(), B, S, eps.data_ptr(), float(c),
         prior_mu.data_ptr(), prior_sigma.data_ptr(), prior_rows,
         mu_q.data_ptr(), sig_q.data_ptr(), ea.data_ptr(), dz.data_ptr(),
         ws.data_ptr(), self._ws_bytes, st)), "oivae_encoder_bwd_f32")
-      _lib.check(self._timed("finalize", lambda: L.oivae_finalize_f32(
-        sh, pt, gt, B, S, float(sigma_theta), float(lam), self.scalars.data_ptr(),
-        ws.data_ptr(), self._ws_bytes, st)), "oivae_finalize_f32")
+      if grad_sync is not None:
+        grad_sync.encoder_grads_ready()
     return dict(mu_q=mu_q, sig_q=sig_q, z=z, scalars=self.scalars, X=X, eps=eps)
 
   def _const(self, name, val):

@@ -67,12 +67,14 @@ class OIVAE(object):
     pm, ps = self._prior()
     for opt in self.optimizers:
       opt.zero_grad()
+    dp = self.data_parallel and parallel.is_active(self.process_group)
+    sync = parallel.BucketedGradSync(eng, self.process_group) if dp else None
     out = eng.forward_backward(X.detach() if torch.is_tensor(X) else X, eps, c, sig_off=sig_off,
                                gen_sig_off=eng.gen_sig_off, prior_mu=pm, prior_sigma=ps,
-                               sigma_theta=float(self.prior_theta.sigma), lam=float(self.lam))
+                               sigma_theta=float(self.prior_theta.sigma), lam=float(self.lam), grad_sync=sync)
     scalars = out["scalars"].clone()
-    if self.data_parallel and parallel.is_active(self.process_group):
-      parallel.allreduce_mean_(eng.flat_grads, self.process_group)
+    if dp:
+      sync.wait()
       parallel.reduce_scalars_(scalars, self.process_group)
     for t, gv in eng.bound:
       t.grad = gv

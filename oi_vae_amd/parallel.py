@@ -42,3 +42,50 @@ def reduce_scalars_(scalars: torch.Tensor, group=None) -> torch.Tensor:
   logprob_W are identical on all ranks and unchanged by the mean; loss and elbo
   are linear in those."""
   return allreduce_mean_(scalars, group)
+
+
+class BucketedGradSync:
+  """Gradient all-reduce in two buckets, overlapped with the backward pass.
+
+  The flat gradient buffer is laid out [encoder | generators, log_sigma, Ws]
+  (engine.py).  The decoder kernel finishes the second part first, so its
+  all-reduce (60 % of the bytes at the scale-up shape) is issued right after it and
+  runs on the communicator's stream while the encoder backward GEMM computes; the
+  encoder part follows.  `wait()` makes the compute stream wait for both and must
+  be called before the optimizers and the proximal step.
+  Collectives are issued in the same order on every rank.  `holder` is anything
+  with `flat_grads` and `seg_off` (an Engine)."""
+
+  def __init__(self, holder, group=None, force=False):
+    self.group = group
+    self.active = force or is_active(group)
+    flat = holder.flat_grads
+    cut = holder.seg_off["gen_W1"]
+    self.flat = flat
+    self.enc = flat[:cut]
+    self.dec = flat[cut:]
+    self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    backend = dist.get_backend(group) if (dist.is_available() and dist.is_initialized()) else ""
+    # RCCL averages in the collective; gloo has no AVG, so sum and scale once in wait()
+    self._avg = backend == "nccl"
+    self._pending = []
+
+  def _issue(self, t):
+    if not self.active or t.numel() == 0:
+      return
+    op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+    self._pending.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
+
+  def decoder_grads_ready(self):
+    self._issue(self.dec)
+
+  def encoder_grads_ready(self):
+    self._issue(self.enc)
+
+  def wait(self):
+    for w in self._pending:
+      w.wait()
+    had = bool(self._pending)
+    self._pending = []
+    if had and not self._avg:
+      self.flat.mul_(1.0 / self.world)

@@ -136,6 +136,14 @@ serr = np.max(np.abs(sc.numpy() - sc_full) / np.maximum(np.abs(sc_full), 1))
 assert err < 2e-6, err
 assert serr < 2e-6, serr
 assert parallel.is_active()
+# the overlapped two-bucket form must give the same mean as the single all-reduce
+class Holder: pass
+h = Holder(); h.flat_grads = torch.from_numpy(g_local.copy()); h.seg_off = {"gen_W1": 1000}
+sync = parallel.BucketedGradSync(h)
+sync.decoder_grads_ready(); sync.encoder_grads_ready(); sync.wait()
+assert torch.equal(h.flat_grads, g), float((h.flat_grads - g).abs().max())
+sync.wait()  # idempotent once drained
+assert torch.equal(h.flat_grads, g)
 dist.destroy_process_group()
 print("rank", rank, "ok", err, serr)
 '''
