@@ -1073,14 +1073,52 @@ __device__ __forceinline__ void mfv0(f32x16& acc, float a_, float b_) {
   asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(a_), "v"(b_));
 }
 
-// one output tile held in VGPRs, NK k-steps
-template <int NK, bool FRESH, class WF, class BF, class VF>
-__device__ __forceinline__ void vphase1(f32x16& acc, WF wf, BF bf, VF vf) {
+// AGPR form (weight-gradient accumulators, never touched by element-wise code).  Also inline asm: with no
+// MFMA visible to it, the compiler's gfx950 peephole that splits v_pk_*_f32 "in the shadow of an MFMA" into two
+// scalar VALU ops (right for bf16 MFMAs, wrong beside fp32 ones) leaves the packed element-wise math alone.
+__device__ __forceinline__ void mfa(f32x16& acc, float a_, float b_) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a_), "v"(b_));
+}
+
+// The three phase shapes below share one convention: the operands of a phase's first k-steps arrive in `w0`,
+// already in flight (issued two slots before the previous phase ended), and each phase issues the first operands
+// of the NEXT phase (`nf(i)`, i < NN, into `wn`) two slots before its own end, so that no phase starts by waiting
+// for an LDS round trip.
+//
+// weight-gradient step on two AGPR tiles that share the A operand: acc0 += af(s)*bf0(s), acc1 += af(s)*bf1(s)
+// w0 = {af(0), bf0(0), bf1(0), af(1), bf0(1), bf1(1)}
+template <int NK, int NN, class AF, class BF0, class BF1, class VF, class NF>
+__device__ __forceinline__ void aphasewg(f32x16& acc0, f32x16& acc1, const float (&w0)[6], AF af, BF0 bf0, BF1 bf1, VF vf,
+                                         NF nf, float (&wn)[NN]) {
+  float wa[NK], wb0[NK], wb1[NK];
+  wa[0] = w0[0]; wb0[0] = w0[1]; wb1[0] = w0[2]; wa[1] = w0[3]; wb0[1] = w0[4]; wb1[1] = w0[5];
+#pragma unroll
+  for (int s = 0; s < NK; ++s) {
+    if (s + 2 < NK) { wa[s + 2] = af(s + 2); wb0[s + 2] = bf0(s + 2); wb1[s + 2] = bf1(s + 2); }
+    if (s == NK - 2) {
+#pragma unroll
+      for (int i = 0; i < NN; ++i) wn[i] = nf(i);
+    }
+    vf(2 * s);
+    mfa(acc0, wa[s], wb0[s]);
+    vf(2 * s + 1);
+    mfa(acc1, wa[s], wb1[s]);
+    OIVAE_SB();
+  }
+}
+
+// one output tile held in VGPRs, NK k-steps.  w0 = {wf(0), wf(1), wf(2)}
+template <int NK, bool FRESH, int NN, class WF, class BF, class VF, class NF>
+__device__ __forceinline__ void vphase1(f32x16& acc, const float (&w0)[3], WF wf, BF bf, VF vf, NF nf, float (&wn)[NN]) {
   float w[NK];
-  w[0] = wf(0); w[1] = wf(1); w[2] = wf(2);
+  w[0] = w0[0]; w[1] = w0[1]; w[2] = w0[2];
 #pragma unroll
   for (int s = 0; s < NK; ++s) {
     if (s + 3 < NK) w[s + 3] = wf(s + 3);
+    if (s == NK - 2) {
+#pragma unroll
+      for (int i = 0; i < NN; ++i) wn[i] = nf(i);
+    }
     vf(s);
     if (FRESH && s == 0) mfv0(acc, w[s], bf(s)); else mfv(acc, w[s], bf(s));
     OIVAE_SB();
@@ -1088,13 +1126,19 @@ __device__ __forceinline__ void vphase1(f32x16& acc, WF wf, BF bf, VF vf) {
 }
 
 // two VGPR output tiles sharing the register operand (accumulating in place); MFMA slot u = 2s+t
-template <int NK, class WF, class BF, class VF>
-__device__ __forceinline__ void vphase2w(f32x16& acc0, f32x16& acc1, WF wf, BF bf, VF vf) {
+// w0 = {wf(0,0), wf(0,1), wf(1,0), wf(1,1)}
+template <int NK, int NN, class WF, class BF, class VF, class NF>
+__device__ __forceinline__ void vphase2w(f32x16& acc0, f32x16& acc1, const float (&w0)[4], WF wf, BF bf, VF vf, NF nf,
+                                         float (&wn)[NN]) {
   float w[NK][2];
-  w[0][0] = wf(0, 0); w[0][1] = wf(0, 1); w[1][0] = wf(1, 0); w[1][1] = wf(1, 1);
+  w[0][0] = w0[0]; w[0][1] = w0[1]; w[1][0] = w0[2]; w[1][1] = w0[3];
 #pragma unroll
   for (int s = 0; s < NK; ++s) {
     if (s + 2 < NK) { w[s + 2][0] = wf(s + 2, 0); w[s + 2][1] = wf(s + 2, 1); }
+    if (s == NK - 2) {
+#pragma unroll
+      for (int i = 0; i < NN; ++i) wn[i] = nf(i);
+    }
     const float b = bf(s);
     vf(2 * s);
     mfv(acc0, w[s][0], b);
@@ -1102,6 +1146,20 @@ __device__ __forceinline__ void vphase2w(f32x16& acc0, f32x16& acc1, WF wf, BF b
     mfv(acc1, w[s][1], b);
     OIVAE_SB();
   }
+}
+
+// Operand reads of the matrix instructions go through LDS-address-space volatile pointers: a volatile read is
+// never merged into ds_read2_b32, whose 8-bit offsets would cost one VALU add (8 matrix cycles) per merged pair.
+using ldsv_t = const volatile float __attribute__((address_space(3)))*;
+
+// Pins a value pair in a 64-bit register pair: the optimizer cannot scalarize arithmetic on it, so
+// the following vector ops select v_pk_*_f32 (one VALU slot for two floats).  Emits no instruction.
+__device__ __forceinline__ f32x2 pin2(f32x2 v) { asm("" : "+v"(v)); return v; }
+// a - b on a register pair in ONE instruction (the compiler expands a v2f32 subtraction into two scalar ones)
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a_, f32x2 b_) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a_), "v"(b_));
+  return r;
 }
 
 __global__ __launch_bounds__(256) void dec_mfma64_v4(MfmaDecArgs a) {
@@ -1161,20 +1219,20 @@ __global__ __launch_bounds__(256) void dec_mfma64_v4(MfmaDecArgs a) {
   float* bufA = sAct + wave * (3 * 32 * LDB);
   float* bufB = bufA + 32 * LDB;
   float* bufZ = bufB + 32 * LDB;
-  const float* pA_r = sAf + l31 * LW + 32 * hh;       // P1: + 32t*LW + s
-  const float* pW2_c = sW2 + l31 * LW + 4 * hh;       // P3: + 32t*LW + 32mt + ROWC
-  const float* pW2_r = sW2 + (4 * hh) * LW + l31;     // P5: + (32dt+ROWC)*LW + 32t
-  const float* pA_c = sAb + (4 * hh) * LW + l31;      // P7: + (32mt+ROWC)*LW + 32t
-  const float* imA = bufA + hh * LDB + l31;
-  const float* imB = bufB + hh * LDB + l31;
-  const float* imZ = bufZ + hh * LDB + l31;
+  const ldsv_t pA_r = (ldsv_t)(sAf + l31 * LW + 32 * hh);       // P1: + 32t*LW + s
+  const ldsv_t pW2_c = (ldsv_t)(sW2 + l31 * LW + 4 * hh);       // P3: + 32t*LW + 32mt + ROWC
+  const ldsv_t pW2_r = (ldsv_t)(sW2 + (4 * hh) * LW + l31);     // P5: + (32dt+ROWC)*LW + 32t
+  const ldsv_t pA_c = (ldsv_t)(sAb + (4 * hh) * LW + l31);      // P7: + (32mt+ROWC)*LW + 32t
+  const ldsv_t imA = (ldsv_t)(bufA + hh * LDB + l31);
+  const ldsv_t imB = (ldsv_t)(bufB + hh * LDB + l31);
+  const ldsv_t imZ = (ldsv_t)(bufZ + hh * LDB + l31);
   float* wrA = bufA + l31 * LDB + 4 * hh;
   float* wrB = bufB + l31 * LDB + 4 * hh;
   float* wrZ = bufZ + l31 * LDB + 32 * hh;
   const float* pb1 = sb1 + 4 * hh;
   const float* pb2 = sb2 + 4 * hh;
   const float* pc3 = sC3 + 4 * hh;
-  const float* csA = bufA + lane;                      // column sums: + row*LDB
+  const ldsv_t csA = (ldsv_t)(bufA + lane);             // column sums: + row*LDB
 
   f32x16 dW2a[2][2], Pa[2][2];
 #pragma unroll
@@ -1223,12 +1281,12 @@ __global__ __launch_bounds__(256) void dec_mfma64_v4(MfmaDecArgs a) {
   char* const dzb = reinterpret_cast<char*>(a.dzT);
   const int64_t rowbytes = a.N * 4;
   uint32_t voff_prev = (uint32_t)((int64_t)(4 * hh) * a.N + n) * 4u;
-  auto none = [](int) {};
+  float w1a[3] = {pA_r[0], pA_r[1], pA_r[2]};  // first operands of the first phase, carried around the loop
 
   for (; tile < ntiles; tile += tstride) {
     const int tnext = (tile + tstride < ntiles) ? tile + tstride : tile;
     const int n_next = row_of(tnext);
-    const bool full = (tile * 32 + 32 <= N32);          // wave-uniform
+    const bool full = (tile * 32 + 32 <= N32);  // wave-uniform: every row of the tile exists (all tiles but possibly the last)
     const float livef = (tile * 32 + l31 < N32) ? 1.0f : 0.0f;
     const f32x4* zp_next = z_ptr(n_next);
     const float* xp_next = x_ptr(n_next);
@@ -1237,25 +1295,34 @@ __global__ __launch_bounds__(256) void dec_mfma64_v4(MfmaDecArgs a) {
       f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
       *reinterpret_cast<f32x4*>(base + 32 * t + 8 * q) = o;
     };
-    auto imrow = [&](const float* im, int col) { return [=](int s) { return im[2 * s * LDB + col]; }; };
+    auto imrow = [&](ldsv_t im, int col) { return [=](int s) { return im[2 * s * LDB + col]; }; };
     // t = 1 - 2/(exp2(arg)+1) on elements 2p, 2p+1 of an accumulator that holds kC*(a1+b1)
     auto tanh_pair = [&](f32x16& acc, int p) {
-      f32x2 e = {__builtin_amdgcn_exp2f(acc[2 * p]), __builtin_amdgcn_exp2f(acc[2 * p + 1])};
-      e = e + 1.0f;
-      f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
-      r = r * (-2.0f) + 1.0f;
+      f32x2 e = pin2(f32x2{__builtin_amdgcn_exp2f(acc[2 * p]), __builtin_amdgcn_exp2f(acc[2 * p + 1])});
+      e = pin2(e + 1.0f);
+      f32x2 r = pin2(f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])});
+      r = pin2(r * (-2.0f) + 1.0f);
       acc[2 * p] = r[0]; acc[2 * p + 1] = r[1];
     };
     // gmu = (mu - x) * inv/sigma^2 on quad q (elements 4q..4q+3) of tile t, then its 16 bytes of the gmu image
+    f32x2 csv = {0.f, 0.f};  // column-sum pair in flight
+    f32x4 c3q[4];  // inv/sigma^2 of the four quads of one tile, fetched one slot before their use
+    auto epi_load = [&](int t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c3q[q] = *reinterpret_cast<const f32x4*>(pc3 + 32 * t + 8 * q);
+    };
     auto epi_quad = [&](int t, int q) {
-      f32x4 c3 = *reinterpret_cast<const f32x4*>(pc3 + 32 * t + 8 * q);
-      if (!full) c3 = c3 * livef;
+      f32x4 c3 = c3q[q];
+      if (!full) {  // a real (scalar) branch: taken by at most one tile of the launch
+        asm volatile("" ::: "memory");
+        c3 = c3 * livef;
+      }
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
-        f32x2 mu = {gacc[t][4 * q + 2 * h2], gacc[t][4 * q + 2 * h2 + 1]};
-        const f32x2 x = {xreg[t][q][2 * h2], xreg[t][q][2 * h2 + 1]};
-        const f32x2 c = {c3[2 * h2], c3[2 * h2 + 1]};
-        mu = (mu - x) * c;
+        f32x2 mu = pin2(f32x2{gacc[t][4 * q + 2 * h2], gacc[t][4 * q + 2 * h2 + 1]});
+        const f32x2 x = pin2(f32x2{xreg[t][q][2 * h2], xreg[t][q][2 * h2 + 1]});
+        const f32x2 c = pin2(f32x2{c3[2 * h2], c3[2 * h2 + 1]});
+        mu = pin2(pk_sub(mu, x) * c);
         gacc[t][4 * q + 2 * h2] = mu[0]; gacc[t][4 * q + 2 * h2 + 1] = mu[1];
       }
       img_store(wrA, gacc[t], t, q);
@@ -1264,78 +1331,84 @@ __global__ __launch_bounds__(256) void dec_mfma64_v4(MfmaDecArgs a) {
     auto da1_quad = [&](int t, int q) {
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
-        const f32x2 tt = {tacc[t][4 * q + 2 * h2], tacc[t][4 * q + 2 * h2 + 1]};
-        f32x2 d = {dacc[t][4 * q + 2 * h2], dacc[t][4 * q + 2 * h2 + 1]};
-        const f32x2 u = 1.0f - tt * tt;
-        d = d * u;
+        const f32x2 tt = pin2(f32x2{tacc[t][4 * q + 2 * h2], tacc[t][4 * q + 2 * h2 + 1]});
+        f32x2 d = pin2(f32x2{dacc[t][4 * q + 2 * h2], dacc[t][4 * q + 2 * h2 + 1]});
+        const f32x2 u = pin2(1.0f - tt * tt);
+        d = pin2(d * u);
         dacc[t][4 * q + 2 * h2] = d[0]; dacc[t][4 * q + 2 * h2 + 1] = d[1];
       }
       img_store(wrA, dacc[t], t, q);
     };
 
-    // ---- P1  kC*(a1+b1)^T = (kC A) z^T + kC b1, tile by tile.  Under tile 0: dz atomics of the previous row tile, z image ----
+    // operand functors of the thirteen phases (k-step s -> LDS operand), and the first loads of each as i -> value
     auto w_p1 = [&](int t) { return [=](int s) { return pA_r[32 * t * LW + s]; }; };
+    auto w_p3a = [&](int s, int t) { return pW2_c[32 * t * LW + OIVAE_ROWC(s)]; };
+    auto w_p3b = [&](int s) { return pW2_c[32 + OIVAE_ROWC(s)]; };
+    auto w_p3c = [&](int s) { return pW2_c[32 * LW + 32 + OIVAE_ROWC(s)]; };
+    auto w_p5 = [&](int t) { return [=](int s) { return pW2_r[(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * LW + 32 * t]; }; };
+    auto w_p7 = [&](int t) { return [=](int s) { return pA_c[(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * LW + 32 * t]; }; };
+    auto wg_first = [&](ldsv_t ia, int ca, ldsv_t ib) {  // {af(0), bf0(0), bf1(0), af(1), bf0(1), bf1(1)}
+      return [=](int i) { const int s = i / 3, j = i % 3; return j == 0 ? ia[2 * s * LDB + ca] : ib[2 * s * LDB + (j == 1 ? 0 : 32)]; };
+    };
     auto b_z = [&](int s) { return zreg[s >> 2][s & 3]; };
-    vphase1<32, false>(tacc[0], w_p1(0), b_z, [&](int s) {
+    auto b_g = [&](int s) { return gacc[s >> 4][s & 15]; };
+    auto b_d = [&](int s) { return dacc[s >> 4][s & 15]; };
+    float c3[3], c4[4], c6[6];  // operand carries between phases (c3 enters holding P1a's first operands)
+    c3[0] = w1a[0]; c3[1] = w1a[1]; c3[2] = w1a[2];
+
+    // ---- P1  kC*(a1+b1)^T = (kC A) z^T + kC b1, tile by tile.  Under tile 0: dz atomics of the previous row tile, z image ----
+    vphase1<32, false>(tacc[0], c3, w_p1(0), b_z, [&](int s) {
       atomicAdd(reinterpret_cast<float*>(dzb + (int64_t)(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * rowbytes + voff_prev),
                 zacc[s >> 4][s & 15]);
       if ((s & 3) == 3) *reinterpret_cast<f32x4*>(wrZ + 4 * (s >> 2)) = zreg[s >> 2];
-    });
-    vphase1<32, false>(tacc[1], w_p1(1), b_z, [&](int s) { if (s >= 2 && s < 10) tanh_pair(tacc[0], s - 2); });
+    }, w_p1(1), c3);
+    vphase1<32, false>(tacc[1], c3, w_p1(1), b_z, [&](int s) { if (s >= 2 && s < 10) tanh_pair(tacc[0], s - 2); },
+                       [&](int i) { return w_p3a(i >> 1, i & 1); }, c4);
     // ---- P3  mu^T = W2 t^T + b2.  k over t tile 0 first (tanh of tile 1 under it) ----
-    vphase2w<16>(gacc[0], gacc[1],
-        [&](int s, int t) { return pW2_c[32 * t * LW + OIVAE_ROWC(s)]; },
-        [&](int s) { return tacc[0][s]; },
-        [&](int u) { if (u >= 2 && u < 10) tanh_pair(tacc[1], u - 2); });
-    vphase1<16, false>(gacc[0], [&](int s) { return pW2_c[32 + OIVAE_ROWC(s)]; },
-                       [&](int s) { return tacc[1][s]; },
-                       [&](int s) { if (s >= 2 && s < 10) img_store(wrB, tacc[(s - 2) >> 2], (s - 2) >> 2, (s - 2) & 3); });  // t image
-    vphase1<16, false>(gacc[1], [&](int s) { return pW2_c[32 * LW + 32 + OIVAE_ROWC(s)]; },
-                       [&](int s) { return tacc[1][s]; },
-                       [&](int s) { if (s >= 2 && s < 6) epi_quad(0, s - 2); });
+    vphase2w<16>(gacc[0], gacc[1], c4, w_p3a, [&](int s) { return tacc[0][s]; },
+                 [&](int u) { if (u >= 2 && u < 10) tanh_pair(tacc[1], u - 2); }, w_p3b, c3);
+    vphase1<16, false>(gacc[0], c3, w_p3b, [&](int s) { return tacc[1][s]; },
+                       [&](int s) { if (s >= 2 && s < 10) img_store(wrB, tacc[(s - 2) >> 2], (s - 2) >> 2, (s - 2) & 3); },  // t image
+                       w_p3c, c3);
+    vphase1<16, false>(gacc[1], c3, w_p3c, [&](int s) { return tacc[1][s]; },
+                       [&](int s) { if (s == 0) epi_load(0); if (s >= 2 && s < 6) epi_quad(0, s - 2); },
+                       wg_first(imA, 0, imB), c6);
     // ---- P4  dW2 += gmu^T t.  rows i=0 first; epilogue of tile 1 and the z prefetch under them ----
-    phasewg<16>(dW2a[0][0], dW2a[0][1], imrow(imA, 0), imrow(imA, 0), imrow(imB, 0), imrow(imB, 32),
-                [&](int u) {
-                  if (u >= 2 && u < 6) epi_quad(1, u - 2);
-                  else if (u >= 8 && u < 16) zreg[u - 8] = zp_next[u - 8];
-                });
-    phasewg<16>(dW2a[1][0], dW2a[1][1], imrow(imA, 32), imrow(imA, 32), imrow(imB, 0), imrow(imB, 32),
-                [&](int u) {
-                  if (!(u & 1)) {
-                    const f32x2 v = {csA[u * LDB], csA[(u + 1) * LDB]};
-                    s1p = s1p + v;
-                    s2p = v * v + s2p;
-                  }
-                });
+    aphasewg<16>(dW2a[0][0], dW2a[0][1], c6, imrow(imA, 0), imrow(imB, 0), imrow(imB, 32),
+                 [&](int u) {
+                   if (u == 0) epi_load(1);
+                   if (u >= 2 && u < 6) epi_quad(1, u - 2);
+                   else if (u >= 8 && u < 16) zreg[u - 8] = zp_next[u - 8];
+                 }, wg_first(imA, 32, imB), c6);
+    aphasewg<16>(dW2a[1][0], dW2a[1][1], c6, imrow(imA, 32), imrow(imB, 0), imrow(imB, 32),
+                 [&](int u) {
+                   if ((!(u & 1) && u >= 2) || u == 31) { const f32x2 v = pin2(csv); s1p = pin2(s1p + v); s2p = pin2(v * v + s2p); }
+                   if (!(u & 1)) csv = f32x2{csA[u * LDB], csA[(u + 1) * LDB]};  // not pinned here: a pin waits for the load
+                 }, w_p5(0), c3);
     // ---- P5  dt^T = W2^T gmu^T tile by tile; x prefetch under tile 0, da1 of tile 0 under tile 1 ----
-    auto w_p5 = [&](int t) { return [=](int s) { return pW2_r[(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * LW + 32 * t]; }; };
-    auto b_g = [&](int s) { return gacc[s >> 4][s & 15]; };
-    vphase1<32, true>(dacc[0], w_p5(0), b_g, [&](int s) {
+    vphase1<32, true>(dacc[0], c3, w_p5(0), b_g, [&](int s) {
       if (s >= 2 && s < 10) xreg[(s - 2) >> 2][(s - 2) & 3] = *reinterpret_cast<const f32x4*>(xp_next + 32 * ((s - 2) >> 2) + 8 * ((s - 2) & 3));
-    });
-    vphase1<32, true>(dacc[1], w_p5(1), b_g, [&](int s) { if (s >= 2 && s < 6) da1_quad(0, s - 2); });
+    }, w_p5(1), c3);
+    vphase1<32, true>(dacc[1], c3, w_p5(1), b_g, [&](int s) { if (s >= 2 && s < 6) da1_quad(0, s - 2); },
+                      wg_first(imA, 0, imZ), c6);
     // ---- P6  P += da1^T z.  rows m 0..31 first; da1 of tile 1 under them ----
-    phasewg<16>(Pa[0][0], Pa[0][1], imrow(imA, 0), imrow(imA, 0), imrow(imZ, 0), imrow(imZ, 32),
-                [&](int u) { if (u >= 2 && u < 6) da1_quad(1, u - 2); });
-    phasewg<16>(Pa[1][0], Pa[1][1], imrow(imA, 32), imrow(imA, 32), imrow(imZ, 0), imrow(imZ, 32),
-                [&](int u) {
-                  if (!(u & 1)) {
-                    const f32x2 v = {csA[u * LDB], csA[(u + 1) * LDB]};
-                    s3p = s3p + v;
-                  }
-                });
+    aphasewg<16>(Pa[0][0], Pa[0][1], c6, imrow(imA, 0), imrow(imZ, 0), imrow(imZ, 32),
+                 [&](int u) { if (u >= 2 && u < 6) da1_quad(1, u - 2); }, wg_first(imA, 32, imZ), c6);
+    aphasewg<16>(Pa[1][0], Pa[1][1], c6, imrow(imA, 32), imrow(imZ, 0), imrow(imZ, 32),
+                 [&](int u) {
+                   if ((!(u & 1) && u >= 2) || u == 31) s3p = pin2(s3p + pin2(csv));
+                   if (!(u & 1)) csv = f32x2{csA[u * LDB], csA[(u + 1) * LDB]};
+                 }, w_p7(0), c3);
     // ---- P7  dz^T = A^T da1^T tile by tile (atomics deferred); the next tile's bias images under them ----
-    auto w_p7 = [&](int t) { return [=](int s) { return pA_c[(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * LW + 32 * t]; }; };
-    auto b_d = [&](int s) { return dacc[s >> 4][s & 15]; };
     voff_prev = (uint32_t)((int64_t)(4 * hh) * a.N + n) * 4u;
-    vphase1<32, true>(zacc[0], w_p7(0), b_d, [&](int s) {
+    vphase1<32, true>(zacc[0], c3, w_p7(0), b_d, [&](int s) {
       if (s == 2) load_bias(gacc[0], pb2, 0);
       if (s == 3) load_bias(gacc[1], pb2, 1);
-    });
-    vphase1<32, true>(zacc[1], w_p7(1), b_d, [&](int s) {
+    }, w_p7(1), c3);
+    vphase1<32, true>(zacc[1], c3, w_p7(1), b_d, [&](int s) {
       if (s == 2) load_bias(tacc[0], pb1, 0);
       if (s == 3) load_bias(tacc[1], pb1, 1);
-    });
+    }, w_p1(0), w1a);
     n = n_next;
   }
   if (had_tiles) {
