@@ -7,8 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# OIVAE_HIP_LIB: path of a diagnostic build of the same library (tools/dec_ablate.sh); never a fallback
-LIB_PATH = os.environ.get("OIVAE_HIP_LIB") or os.path.join(_HERE, "liboivae_hip.so")
+LIB_PATH = os.path.join(_HERE, "liboivae_hip.so")
 
 c_f = ctypes.c_float
 c_i32 = ctypes.c_int32

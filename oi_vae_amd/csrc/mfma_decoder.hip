@@ -420,626 +420,12 @@ __global__ __launch_bounds__(256) void dec_mfma(MfmaDecArgs a) {
 }
 
 
-// ==============================================================================
-// v2 of the all-64 kernel: same math and data flow as dec_mfma<64,64,64,64>, with
-// the instruction stream laid out by hand so that the matrix pipe never waits:
-//   * every MFMA's LDS operand is fetched two k-steps ahead (counted lgkmcnt);
-//   * each product is split per 32x32 output tile so that the element-wise work
-//     on a finished tile (tanh, residual epilogue, (1-t^2) scaling), the LDS image
-//     stores, the column sums, the dz atomics and the next tile's global loads
-//     are issued one small chunk per MFMA slot, under the shadow of the 64-cycle
-//     MFMAs of the neighbouring tile (one wave per SIMD issues in order);
-//   * accumulators start from an inline zero C operand instead of v_mov chains;
-//   * x and z of the next row tile are prefetched as soon as their registers die.
-// sched_barrier(0) after every k-step pins this order against the scheduler.
-// ==============================================================================
 #define OIVAE_SB() __builtin_amdgcn_sched_barrier(0)
 #define OIVAE_ROWC(r) (((r) & 3) + 8 * ((r) >> 2))
 
 __device__ __forceinline__ f32x16 mf32(float a_, float b_, f32x16 c_) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, c_, 0, 0, 0);
 }
-
-// one output tile, NK k-steps; wf(s) = LDS weight operand, bf(s) = register operand, vf(s) = VALU chunk
-template <int NK, bool FRESH, class WF, class BF, class VF>
-__device__ __forceinline__ void phase1(f32x16& acc, WF wf, BF bf, VF vf) {
-  float w[NK];
-  w[0] = wf(0); w[1] = wf(1); w[2] = wf(2);
-#pragma unroll
-  for (int s = 0; s < NK; ++s) {
-    if (s + 3 < NK) w[s + 3] = wf(s + 3);
-    vf(s);
-    acc = mf32(w[s], bf(s), (FRESH && s == 0) ? (f32x16)(0.f) : acc);
-    OIVAE_SB();
-  }
-}
-
-// two output tiles sharing the register operand: acc0 += w0*b, acc1 += w1*b; MFMA slot u = 2s+t
-template <int NK, bool FRESH, class WF, class BF, class VF>
-__device__ __forceinline__ void phase2w(f32x16& acc0, f32x16& acc1, WF wf, BF bf, VF vf) {
-  float w[NK][2];
-  w[0][0] = wf(0, 0); w[0][1] = wf(0, 1); w[1][0] = wf(1, 0); w[1][1] = wf(1, 1);
-#pragma unroll
-  for (int s = 0; s < NK; ++s) {
-    if (s + 2 < NK) { w[s + 2][0] = wf(s + 2, 0); w[s + 2][1] = wf(s + 2, 1); }
-    const float b = bf(s);
-    vf(2 * s);
-    acc0 = mf32(w[s][0], b, (FRESH && s == 0) ? (f32x16)(0.f) : acc0);
-    vf(2 * s + 1);
-    acc1 = mf32(w[s][1], b, (FRESH && s == 0) ? (f32x16)(0.f) : acc1);
-    OIVAE_SB();
-  }
-}
-
-// weight-gradient step: both operands come from the wave's LDS images.
-// acc0 += af0(s)*bf0(s), acc1 += af1(s)*bf1(s)   (callers pass identical af or bf for the shared side)
-template <int NK, class AF0, class AF1, class BF0, class BF1, class VF>
-__device__ __forceinline__ void phasewg(f32x16& acc0, f32x16& acc1, AF0 af0, AF1 af1, BF0 bf0, BF1 bf1, VF vf) {
-  float wa0[NK], wa1[NK], wb0[NK], wb1[NK];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) { wa0[s] = af0(s); wa1[s] = af1(s); wb0[s] = bf0(s); wb1[s] = bf1(s); }
-#pragma unroll
-  for (int s = 0; s < NK; ++s) {
-    if (s + 2 < NK) { wa0[s + 2] = af0(s + 2); wa1[s + 2] = af1(s + 2); wb0[s + 2] = bf0(s + 2); wb1[s + 2] = bf1(s + 2); }
-    vf(2 * s);
-    acc0 = mf32(wa0[s], wb0[s], acc0);
-    vf(2 * s + 1);
-    acc1 = mf32(wa1[s], wb1[s], acc1);
-    OIVAE_SB();
-  }
-}
-
-__global__ __launch_bounds__(256) void dec_mfma64_v2(MfmaDecArgs a) {
-  constexpr int K = 64, H = 64, M = 64, DG = 64;
-  constexpr int LW = 65, LDB = 68;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* sWs = reinterpret_cast<float*>(smem_raw);
-  float* sW1 = sWs + K * LW;
-  float* sW2 = sW1 + M * LW;
-  float* sb1 = sW2 + DG * LW;
-  float* sb2 = sb1 + M;
-  float* sIsig = sb2 + DG;
-  float* sC2 = sIsig + DG;
-  float* sAct = sC2 + DG;
-
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-  const int g = blockIdx.x, chunk = blockIdx.y, nchunks = gridDim.y;
-  {
-    const float* Wsg = a.Ws + (int64_t)g * K * H;
-    for (int i = tid; i < K * H; i += 256) sWs[(i / H) * LW + (i % H)] = Wsg[i];
-    const float* W1g = a.W1 + (int64_t)g * M * H;
-    for (int i = tid; i < M * H; i += 256) sW1[(i / H) * LW + (i % H)] = W1g[i];
-    const float* W2g = a.W2 + (int64_t)g * DG * M;
-    for (int i = tid; i < DG * M; i += 256) sW2[(i / M) * LW + (i % M)] = W2g[i];
-    for (int i = tid; i < M; i += 256) sb1[i] = a.b1[(int64_t)g * M + i];
-    for (int i = tid; i < DG; i += 256) {
-      const float sg = expf(a.ls[(int64_t)g * DG + i]) + a.sig_off;
-      sb2[i] = a.b2[(int64_t)g * DG + i];
-      sIsig[i] = 1.0f / sg;
-      sC2[i] = a.inv / sg;
-    }
-  }
-  __syncthreads();
-
-  float* bufA = sAct + wave * (2 * 32 * LDB);
-  float* bufB = bufA + 32 * LDB;
-  // per-lane operand bases
-  const float* pWs_g1 = sWs + (hh * 32) * LW + l31;   // G1: + s*LW + 32t          (Ws[k][h], lanes over h)
-  const float* pW1_c = sW1 + l31 * LW + 4 * hh;       // G2: + 32t*LW + 32ht+ROWC  (W1[m][h], lanes over m)
-  const float* pW2_c = sW2 + l31 * LW + 4 * hh;       // G3: + 32t*LW + 32mt+ROWC  (W2[d][m], lanes over d)
-  const float* pW2_r = sW2 + (4 * hh) * LW + l31;     // G5: + (32dt+ROWC)*LW + 32t (lanes over m)
-  const float* pW1_r = sW1 + (4 * hh) * LW + l31;     // G6: + (32mt+ROWC)*LW + 32t (lanes over h)
-  const float* pWs_c = sWs + l31 * LW + 4 * hh;       // G7: + 32t*LW + 32ht+ROWC  (lanes over k)
-  const float* imA = bufA + hh * LDB + l31;           // image operand reads: + 2s*LDB + 32t
-  const float* imB = bufB + hh * LDB + l31;
-  float* wrA = bufA + l31 * LDB + 4 * hh;             // image stores: + 32t + 8q (16 bytes)
-  float* wrB = bufB + l31 * LDB + 4 * hh;
-  const float* pb1 = sb1 + 4 * hh;                    // + 32t + 8q
-  const float* pb2 = sb2 + 4 * hh;
-  const float* pis = sIsig + 4 * hh;
-  const float* pc2 = sC2 + 4 * hh;
-
-  f32x16 dW2a[2][2], dW1a[2][2], dWsa[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { dW2a[i][j] = (f32x16)(0.f); dW1a[i][j] = (f32x16)(0.f); dWsa[i][j] = (f32x16)(0.f); }
-  float cs_gmu = 0.f, cs_gmu2 = 0.f, cs_da1 = 0.f;
-
-  const int64_t ntiles = (a.N + 31) / 32;
-  const int64_t tstride = 4 * (int64_t)nchunks;
-  int64_t tile = (int64_t)chunk * 4 + wave;
-  int64_t n = tile * 32 + l31;
-  bool live = n < a.N;
-  f32x4 zreg[8], xreg[2][4];
-  auto load_z = [&](int64_t nn, bool lv) {
-    const f32x4* zp = reinterpret_cast<const f32x4*>(a.z + (lv ? nn : 0) * K + hh * 32);
-#pragma unroll
-    for (int v = 0; v < 8; ++v) zreg[v] = lv ? zp[v] : (f32x4)(0.f);
-  };
-  auto load_x = [&](int64_t nn, bool lv) {
-    int64_t xr = lv ? nn : 0;
-    if (xr >= a.B) xr %= a.B;
-    const float* xp = a.X + xr * (int64_t)a.D + (int64_t)g * DG + 4 * hh;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) xreg[dt][q] = *reinterpret_cast<const f32x4*>(xp + 32 * dt + 8 * q);
-  };
-  if (tile < ntiles) { load_z(n, live); load_x(n, live); }
-  auto none = [](int) {};
-
-  for (; tile < ntiles; tile += tstride) {
-    const int64_t n_next = (tile + tstride) * 32 + l31;
-    const bool has_next = (tile + tstride) < ntiles;
-    const bool live_next = has_next && (n_next < a.N);
-    const float livef = live ? 1.0f : 0.0f;
-    f32x16 hacc[2], tacc[2], gacc[2], dacc[2], eacc[2], zacc[2];
-    f32x4 cA, cB, cC;  // per-quad constants of the element-wise chunks
-
-    // ---- P1  G1: h^T = Ws^T z^T (two tiles share z) ----
-    phase2w<32, true>(hacc[0], hacc[1],
-        [&](int s, int t) { return pWs_g1[s * LW + 32 * t]; },
-        [&](int s) { return zreg[s >> 2][s & 3]; }, none);
-    // ---- P2  G2: a1^T = W1 h^T, tile by tile; tanh of tile 0 under tile 1 ----
-    auto w_g2 = [&](int t) { return [=](int s) { return pW1_c[32 * t * LW + 32 * (s >> 4) + OIVAE_ROWC(s & 15)]; }; };
-    auto b_h = [&](int s) { return hacc[s >> 4][s & 15]; };
-    auto tanh_chunk = [&](int t, int e) {  // element e (0..15) of tile t: add bias, tanh
-      if ((e & 3) == 0) cA = *reinterpret_cast<const f32x4*>(pb1 + 32 * t + 8 * (e >> 2));
-      tacc[t][e] = fast_tanh(tacc[t][e] + cA[e & 3]);
-    };
-    phase1<32, true>(tacc[0], w_g2(0), b_h, none);
-    phase1<32, true>(tacc[1], w_g2(1), b_h, [&](int s) { if (!(s & 1)) tanh_chunk(0, s >> 1); });
-    // ---- P3  G3: mu^T = W2 t^T.  k-steps over t tile 0 first (tanh of tile 1 under them) ----
-    phase2w<16, true>(gacc[0], gacc[1],
-        [&](int s, int t) { return pW2_c[32 * t * LW + OIVAE_ROWC(s)]; },
-        [&](int s) { return tacc[0][s]; },
-        [&](int u) { if (!(u & 1)) tanh_chunk(1, u >> 1); });
-    auto img_store = [&](float* base, const f32x16& v, int t, int q) {
-      f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-      *reinterpret_cast<f32x4*>(base + 32 * t + 8 * q) = o;
-    };
-    phase1<16, false>(gacc[0], [&](int s) { return pW2_c[32 + OIVAE_ROWC(s)]; },
-                      [&](int s) { return tacc[1][s]; },
-                      [&](int s) { if (s < 8) img_store(wrB, tacc[s >> 2], s >> 2, s & 3); });  // t image -> bufB
-    auto epi_chunk = [&](int t, int e) {  // residual -> dL/dmu for element e of tile t
-      if ((e & 3) == 0) {
-        cA = *reinterpret_cast<const f32x4*>(pb2 + 32 * t + 8 * (e >> 2));
-        cB = *reinterpret_cast<const f32x4*>(pis + 32 * t + 8 * (e >> 2));
-        cC = *reinterpret_cast<const f32x4*>(pc2 + 32 * t + 8 * (e >> 2));
-      }
-      const float qv = (xreg[t][e >> 2][e & 3] - (gacc[t][e] + cA[e & 3])) * cB[e & 3];
-      gacc[t][e] = -(qv * cC[e & 3]) * livef;
-      if ((e & 3) == 3) img_store(wrA, gacc[t], t, e >> 2);  // gmu image -> bufA
-    };
-    phase1<16, false>(gacc[1], [&](int s) { return pW2_c[32 * LW + 32 + OIVAE_ROWC(s)]; },
-                      [&](int s) { return tacc[1][s]; },
-                      [&](int s) { epi_chunk(0, s); });
-    // ---- P4  W1: dW2 += gmu^T t.  rows i=0 first; epilogue of tile 1 and the x prefetch under them ----
-    auto imrow = [&](const float* im, int col) { return [=](int s) { return im[2 * s * LDB + col]; }; };
-    phasewg<16>(dW2a[0][0], dW2a[0][1], imrow(imA, 0), imrow(imA, 0), imrow(imB, 0), imrow(imB, 32),
-                [&](int u) { if (!(u & 1)) epi_chunk(1, u >> 1); });
-    if (has_next) load_x(n_next, live_next);
-    float s1 = 0.f, s2 = 0.f;
-    phasewg<16>(dW2a[1][0], dW2a[1][1], imrow(imA, 32), imrow(imA, 32), imrow(imB, 0), imrow(imB, 32),
-                [&](int u) { const float v = bufA[u * LDB + lane]; s1 += v; s2 = fmaf(v, v, s2); });
-    cs_gmu += s1; cs_gmu2 += s2;
-    // ---- P5  G5: dt^T = W2^T gmu^T tile by tile; da1 of tile 0 and the images under tile 1 ----
-    auto w_g5 = [&](int t) { return [=](int s) { return pW2_r[(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * LW + 32 * t]; }; };
-    auto b_g = [&](int s) { return gacc[s >> 4][s & 15]; };
-    phase1<32, true>(dacc[0], w_g5(0), b_g, none);
-    phase1<32, true>(dacc[1], w_g5(1), b_g, [&](int s) {
-      if (s < 16) {
-        dacc[0][s] = dacc[0][s] * (1.0f - tacc[0][s] * tacc[0][s]);
-        if ((s & 3) == 3) img_store(wrA, dacc[0], 0, s >> 2);      // da1 tile 0 -> bufA
-      } else if (s < 24) {
-        img_store(wrB, hacc[(s - 16) >> 2], (s - 16) >> 2, (s - 16) & 3);  // h image -> bufB
-      }
-    });
-    // ---- P6  W2: dW1 += da1^T h ----
-    phasewg<16>(dW1a[0][0], dW1a[0][1], imrow(imA, 0), imrow(imA, 0), imrow(imB, 0), imrow(imB, 32),
-                [&](int u) {
-                  if (!(u & 1)) {
-                    const int e = u >> 1;
-                    dacc[1][e] = dacc[1][e] * (1.0f - tacc[1][e] * tacc[1][e]);
-                    if ((e & 3) == 3) img_store(wrA, dacc[1], 1, e >> 2);
-                  }
-                });
-    float s3 = 0.f;
-    phasewg<16>(dW1a[1][0], dW1a[1][1], imrow(imA, 32), imrow(imA, 32), imrow(imB, 0), imrow(imB, 32),
-                [&](int u) { s3 += bufA[u * LDB + lane]; });
-    cs_da1 += s3;
-    // ---- P7  G6: dh^T = W1^T da1^T tile by tile; dh/z images and the z prefetch under tile 1 ----
-    auto w_g6 = [&](int t) { return [=](int s) { return pW1_r[(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * LW + 32 * t]; }; };
-    auto b_d = [&](int s) { return dacc[s >> 4][s & 15]; };
-    phase1<32, true>(eacc[0], w_g6(0), b_d, none);
-    phase1<32, true>(eacc[1], w_g6(1), b_d, [&](int s) {
-      if (s < 4) img_store(wrB, eacc[0], 0, s);                                    // dh tile 0 -> bufB
-      else if (s < 12) *reinterpret_cast<f32x4*>(bufA + l31 * LDB + hh * 32 + 4 * (s - 4)) = zreg[s - 4];  // z -> bufA
-    });
-    if (has_next) load_z(n_next, live_next);
-    // ---- P8  W3: dWs += z^T dh.  columns j=0 first; dh tile 1 image under them ----
-    phasewg<16>(dWsa[0][0], dWsa[1][0], imrow(imA, 0), imrow(imA, 32), imrow(imB, 0), imrow(imB, 0),
-                [&](int u) { if (u < 4) img_store(wrB, eacc[1], 1, u); });
-    phasewg<16>(dWsa[0][1], dWsa[1][1], imrow(imA, 0), imrow(imA, 32), imrow(imB, 32), imrow(imB, 32), none);
-    // ---- P9  G7: dz^T = Ws dh^T tile by tile; atomics of tile 0 under tile 1 ----
-    auto w_g7 = [&](int t) { return [=](int s) { return pWs_c[32 * t * LW + 32 * (s >> 4) + OIVAE_ROWC(s & 15)]; }; };
-    auto b_e = [&](int s) { return eacc[s >> 4][s & 15]; };
-    float* dzp = a.dzT + (int64_t)(4 * hh) * a.N + (live ? n : 0);
-    phase1<32, true>(zacc[0], w_g7(0), b_e, none);
-    phase1<32, true>(zacc[1], w_g7(1), b_e, [&](int s) {
-      if (!(s & 1) && live) atomicAdd(dzp + (int64_t)OIVAE_ROWC(s >> 1) * a.N, zacc[0][s >> 1]);
-    });
-    if (live) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) atomicAdd(dzp + (int64_t)(32 + OIVAE_ROWC(r)) * a.N, zacc[1][r]);
-    }
-    n = n_next;
-    live = live_next;
-  }
-
-  // ---- reduce the four waves' partials in a fixed order and store (as v1) ----
-  const int64_t cs = a.chunk_stride * chunk;
-  float* stage = sAct;
-  auto reduce_store = [&](f32x16 (&acc)[2][2], float* dst) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          stage[wave * 4096 + (32 * i + OIVAE_ROW(r, hh)) * 64 + 32 * j + l31] = acc[i][j][r];
-    __syncthreads();
-    for (int idx = tid; idx < 4096; idx += 256) {
-      float s = stage[idx];
-      s += stage[4096 + idx];
-      s += stage[2 * 4096 + idx];
-      s += stage[3 * 4096 + idx];
-      dst[idx] = s;
-    }
-  };
-  reduce_store(dW2a, a.gW2 + cs + (int64_t)g * DG * M);
-  reduce_store(dW1a, a.gW1 + cs + (int64_t)g * M * H);
-  reduce_store(dWsa, a.gWs + cs + (int64_t)g * K * H);
-  __syncthreads();
-  stage[wave * 192 + lane] = cs_gmu;
-  stage[wave * 192 + 64 + lane] = cs_gmu2;
-  stage[wave * 192 + 128 + lane] = cs_da1;
-  __syncthreads();
-  float* sred = stage + 1024;
-  if (tid < 64) {
-    const float s_gmu = ((stage[tid] + stage[192 + tid]) + stage[384 + tid]) + stage[576 + tid];
-    const float s_gmu2 = ((stage[64 + tid] + stage[256 + tid]) + stage[448 + tid]) + stage[640 + tid];
-    const float s_da1 = ((stage[128 + tid] + stage[320 + tid]) + stage[512 + tid]) + stage[704 + tid];
-    const int64_t d = (int64_t)g * DG + tid;
-    const float e = expf(a.ls[d]);
-    const float sg = e + a.sig_off;
-    const float c2 = a.inv / sg;
-    const float sumq2 = s_gmu2 / (c2 * c2);
-    const float nrows = (chunk == 0) ? (float)a.N : 0.f;
-    a.gb2[cs + d] = s_gmu;
-    a.gls[cs + d] = (nrows - sumq2) * (e * a.inv / sg);
-    a.gb1[cs + (int64_t)g * M + tid] = s_da1;
-    sred[tid] = nrows * (-0.5f * kLog2Pi - logf(sg)) - 0.5f * sumq2;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double tot = 0.0;
-    for (int i = 0; i < 64; ++i) tot += (double)sred[i];
-    a.ll_part[(int64_t)chunk * gridDim.x + g] = tot;
-  }
-}
-
-
-// ==============================================================================
-// v3 of the all-64 kernel: composed first layer.
-//
-// Between h = z Ws[g] and a1 = W1 h + b1 there is no nonlinearity
-// (/root/reference/lib/models.py:93 feeds z @ Ws[i] straight into the generator's
-// first nn.Linear), so per group the two maps compose: with A = W1 Ws^T  [M, K]
-//     a1  = A z + b1                      (forward, one product instead of two)
-//     dz  = A^T da1                       (one product instead of two)
-//     P   = sum_rows da1^T z   [M, K]     (ONE weight-gradient product in the row loop)
-//     dW1 = P Ws,   dWs = P^T W1          (two 64^3 products per GROUP, after the loop)
-// Six 32-row products per tile instead of nine (384 MFMAs, 24.6k cycles), identical
-// mathematics; rounding differs from the layer-by-layer order at the 1e-7 level.
-// A is built once per workgroup on the matrix cores (4 tiles, one per wave).
-//
-// Instruction stream as v2, plus:
-//   * the body is branch free: ragged last tiles are handled by clamped addresses and a
-//     0/1 multiplier, "no next tile" by re-fetching the current one;
-//   * the dz atomics of tile i are issued at the START of tile i+1 (under its first
-//     product) and the prefetch loads later in the tile, so that the wait for the
-//     prefetched z at the top of the loop never waits for an atomic (which takes ~3k
-//     cycles to retire under load);
-//   * z gets an LDS image of its own, written at the start of the tile, which frees its
-//     registers for the prefetch after the first product.
-// ==============================================================================
-// ABL != 0 exists only in diagnostic builds (-DOIVAE_DIAG_VARIANTS, tools/dec_ablate.sh): each bit drops one class of
-// non-MFMA work so that its un-hidden cost can be timed; the results of such a launch are meaningless.
-template <int ABL>
-__global__ __launch_bounds__(256) void dec_mfma64_v3(MfmaDecArgs a) {
-  constexpr int K = 64, H = 64, M = 64, DG = 64;
-  constexpr int LW = 65, LDB = 68;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* sA = reinterpret_cast<float*>(smem_raw);  // A[m][k] = sum_h W1[m][h] Ws[k][h]
-  float* sW2 = sA + M * LW;
-  float* sb1 = sW2 + DG * LW;
-  float* sb2 = sb1 + M;
-  float* sC3 = sb2 + DG;    // inv / sigma_d^2
-  float* sPad = sC3 + DG;   // (keeps the images 16-byte aligned)
-  float* sAct = sPad + 64;  // 4 waves x 3 images x [32][LDB]
-
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-  const int g = blockIdx.x, chunk = blockIdx.y, nchunks = gridDim.y;
-  const float* Wsg = a.Ws + (int64_t)g * K * H;
-  const float* W1g = a.W1 + (int64_t)g * M * H;
-  // ---- prologue: stage W1, Ws (temporarily, in the image area) and W2; A = W1 Ws^T ----
-  float* tW1 = sAct;
-  float* tWs = sAct + 64 * LW;
-  {
-    const float* W2g = a.W2 + (int64_t)g * DG * M;
-    for (int i = tid; i < 4096; i += 256) {
-      const int o = (i >> 6) * LW + (i & 63);
-      tW1[o] = W1g[i];
-      tWs[o] = Wsg[i];
-      sW2[o] = W2g[i];
-    }
-    if (tid < 64) {
-      const float sg = expf(a.ls[(int64_t)g * DG + tid]) + a.sig_off;
-      sb1[tid] = a.b1[(int64_t)g * M + tid];
-      sb2[tid] = a.b2[(int64_t)g * DG + tid];
-      sC3[tid] = (a.inv / sg) / sg;
-    }
-  }
-  __syncthreads();
-  {
-    const int mt = wave >> 1, kt = wave & 1;
-    f32x16 acc = (f32x16)(0.f);
-    const float* pa = tW1 + (32 * mt + l31) * LW + hh;
-    const float* pb = tWs + (32 * kt + l31) * LW + hh;
-#pragma unroll 8
-    for (int s = 0; s < 32; ++s) acc = mf32(pa[2 * s], pb[2 * s], acc);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sA[(32 * mt + OIVAE_ROW(r, hh)) * LW + 32 * kt + l31] = acc[r];
-  }
-  __syncthreads();
-
-  float* bufA = sAct + wave * (3 * 32 * LDB);
-  float* bufB = bufA + 32 * LDB;
-  float* bufZ = bufB + 32 * LDB;
-  const float* pA_r = sA + l31 * LW + 32 * hh;        // P1: + 32t*LW + s            (A[m][k], lanes over m)
-  const float* pW2_c = sW2 + l31 * LW + 4 * hh;       // P3: + 32t*LW + 32mt + ROWC  (W2[d][m], lanes over d)
-  const float* pW2_r = sW2 + (4 * hh) * LW + l31;     // P5: + (32dt+ROWC)*LW + 32t  (lanes over m)
-  const float* pA_c = sA + (4 * hh) * LW + l31;       // P7: + (32mt+ROWC)*LW + 32t  (lanes over k)
-  const float* imA = bufA + hh * LDB + l31;           // image operand reads: + 2s*LDB + 32t
-  const float* imB = bufB + hh * LDB + l31;
-  const float* imZ = bufZ + hh * LDB + l31;
-  float* wrA = bufA + l31 * LDB + 4 * hh;             // image stores: + 32t + 8q (16 bytes)
-  float* wrB = bufB + l31 * LDB + 4 * hh;
-  float* wrZ = bufZ + l31 * LDB + 32 * hh;            // z image: + 4v
-  const float* pb1 = sb1 + 4 * hh;                    // + 32t + 8q
-  const float* pb2 = sb2 + 4 * hh;
-  const float* pc3 = sC3 + 4 * hh;
-
-  f32x16 dW2a[2][2], Pa[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { dW2a[i][j] = (f32x16)(0.f); Pa[i][j] = (f32x16)(0.f); }
-  float cs_gmu = 0.f, cs_gmu2 = 0.f, cs_da1 = 0.f;
-
-  const int64_t ntiles = (a.N + 31) / 32;
-  const int64_t tstride = 4 * (int64_t)nchunks;
-  int64_t tile = (int64_t)chunk * 4 + wave;
-  const bool had_tiles = tile < ntiles;
-  f32x4 zreg[8], xreg[2][4];
-  f32x16 zacc[2];
-  zacc[0] = (f32x16)(0.f);
-  zacc[1] = (f32x16)(0.f);
-  auto row_of = [&](int64_t t) {  // this lane's (clamped) row of tile t
-    const int64_t n = t * 32 + l31;
-    return n < a.N ? n : a.N - 1;
-  };
-  auto z_ptr = [&](int64_t nn) { return reinterpret_cast<const f32x4*>(a.z + nn * K + hh * 32); };
-  const bool one_sample = (a.N == a.B);  // S == 1: row n of z pairs with row n of X, no 64-bit modulo in the loop
-  auto x_ptr = [&](int64_t nn) {
-    const int64_t xr = one_sample ? nn : nn % a.B;
-    return a.X + xr * (int64_t)a.D + (int64_t)g * DG + 4 * hh;
-  };
-  int64_t n = row_of(had_tiles ? tile : 0);
-  bool live = had_tiles && (tile * 32 + l31 < a.N);
-  {
-    const f32x4* zp = z_ptr(n);
-#pragma unroll
-    for (int v = 0; v < 8; ++v) zreg[v] = zp[v];
-    const float* xp = x_ptr(n);
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) xreg[dt][q] = *reinterpret_cast<const f32x4*>(xp + 32 * dt + 8 * q);
-  }
-  float* dzp_prev = a.dzT + (int64_t)(4 * hh) * a.N + n;  // first tile: adds zeros to its own rows
-  auto none = [](int) {};
-
-  for (; tile < ntiles; tile += tstride) {
-    const int64_t tnext = (tile + tstride < ntiles) ? tile + tstride : tile;
-    const int64_t n_next = row_of(tnext);
-    const bool live_next = tnext * 32 + l31 < a.N;
-    const float livef = live ? 1.0f : 0.0f;
-    const f32x4* zp_next = z_ptr(n_next);
-    const float* xp_next = x_ptr(n_next);
-    f32x16 tacc[2], gacc[2], dacc[2];
-    f32x4 cA, cB;
-
-    auto img_store = [&](float* base, const f32x16& v, int t, int q) {
-      if (ABL & 8) return;
-      f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-      *reinterpret_cast<f32x4*>(base + 32 * t + 8 * q) = o;
-    };
-    auto imrow = [&](const float* im, int col) { return [=](int s) { return im[2 * s * LDB + col]; }; };
-
-    // ---- P1  a1^T = A z^T, tile by tile.  Under tile 0: dz atomics of the PREVIOUS row tile and the z image ----
-    auto w_p1 = [&](int t) { return [=](int s) { return pA_r[32 * t * LW + s]; }; };
-    auto b_z = [&](int s) { return zreg[s >> 2][s & 3]; };
-    auto tanh_chunk = [&](int t, int e) {
-      if ((e & 3) == 0) cA = *reinterpret_cast<const f32x4*>(pb1 + 32 * t + 8 * (e >> 2));
-      if (ABL & 2) tacc[t][e] = tacc[t][e] + cA[e & 3];
-      else tacc[t][e] = fast_tanh(tacc[t][e] + cA[e & 3]);
-    };
-    phase1<32, true>(tacc[0], w_p1(0), b_z, [&](int s) {
-      if (!(ABL & 1)) atomicAdd(dzp_prev + (int64_t)(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * a.N, zacc[s >> 4][s & 15]);
-      if (!(ABL & 8)) if ((s & 3) == 3) *reinterpret_cast<f32x4*>(wrZ + 4 * (s >> 2)) = zreg[s >> 2];
-    });
-    phase1<32, true>(tacc[1], w_p1(1), b_z, [&](int s) { if ((s & 1) && s < 32) tanh_chunk(0, s >> 1); });
-    // ---- P3  mu^T = W2 t^T.  k over t tile 0 first (tanh of tile 1 under it) ----
-    phase2w<16, true>(gacc[0], gacc[1],
-        [&](int s, int t) { return pW2_c[32 * t * LW + OIVAE_ROWC(s)]; },
-        [&](int s) { return tacc[0][s]; },
-        [&](int u) { if (u & 1) tanh_chunk(1, u >> 1); });
-    phase1<16, false>(gacc[0], [&](int s) { return pW2_c[32 + OIVAE_ROWC(s)]; },
-                      [&](int s) { return tacc[1][s]; },
-                      [&](int s) { if (s >= 1 && s < 9) img_store(wrB, tacc[(s - 1) >> 2], (s - 1) >> 2, (s - 1) & 3); });  // t image
-    auto epi_chunk = [&](int t, int e) {  // gmu = (mu - x) * inv/sigma^2 for element e of tile t
-      if ((e & 3) == 0) {
-        cA = *reinterpret_cast<const f32x4*>(pb2 + 32 * t + 8 * (e >> 2));
-        cB = *reinterpret_cast<const f32x4*>(pc3 + 32 * t + 8 * (e >> 2));
-      }
-      if (ABL & 16) gacc[t][e] = gacc[t][e] * livef;
-      else gacc[t][e] = ((gacc[t][e] + cA[e & 3]) - xreg[t][e >> 2][e & 3]) * (cB[e & 3] * livef);
-      if ((e & 3) == 3) img_store(wrA, gacc[t], t, e >> 2);  // gmu image
-    };
-    phase1<16, false>(gacc[1], [&](int s) { return pW2_c[32 * LW + 32 + OIVAE_ROWC(s)]; },
-                      [&](int s) { return tacc[1][s]; },
-                      [&](int s) { if (s >= 1 && s < 9) { epi_chunk(0, 2 * (s - 1)); epi_chunk(0, 2 * (s - 1) + 1); } });
-    // ---- P4  dW2 += gmu^T t.  rows i=0 first; epilogue of tile 1 and the z prefetch under them ----
-    phasewg<16>(dW2a[0][0], dW2a[0][1], imrow(imA, 0), imrow(imA, 0), imrow(imB, 0), imrow(imB, 32),
-                [&](int u) {
-                  if (u >= 2 && u < 18) epi_chunk(1, u - 2);
-                  else if (!(ABL & 32) && u >= 18 && u < 26) zreg[u - 18] = zp_next[u - 18];
-                });
-    float s1 = 0.f, s2 = 0.f;
-    phasewg<16>(dW2a[1][0], dW2a[1][1], imrow(imA, 32), imrow(imA, 32), imrow(imB, 0), imrow(imB, 32),
-                [&](int u) { if (!(ABL & 4)) { const float v = bufA[u * LDB + lane]; s1 += v; s2 = fmaf(v, v, s2); } });
-    cs_gmu += s1; cs_gmu2 += s2;
-    // ---- P5  dt^T = W2^T gmu^T tile by tile; x prefetch under tile 0, da1 of tile 0 under tile 1 ----
-    auto w_p5 = [&](int t) { return [=](int s) { return pW2_r[(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * LW + 32 * t]; }; };
-    auto b_g = [&](int s) { return gacc[s >> 4][s & 15]; };
-    phase1<32, true>(dacc[0], w_p5(0), b_g, [&](int s) {
-      if (!(ABL & 32) && s >= 2 && s < 10) xreg[(s - 2) >> 2][(s - 2) & 3] = *reinterpret_cast<const f32x4*>(xp_next + 32 * ((s - 2) >> 2) + 8 * ((s - 2) & 3));
-    });
-    auto da1_chunk = [&](int t, int e) {
-      if (!(ABL & 64)) dacc[t][e] = dacc[t][e] * (1.0f - tacc[t][e] * tacc[t][e]);
-      if ((e & 3) == 3) img_store(wrA, dacc[t], t, e >> 2);
-    };
-    phase1<32, true>(dacc[1], w_p5(1), b_g, [&](int s) { if (s >= 1 && s < 17) da1_chunk(0, s - 1); });
-    // ---- P6  P += da1^T z.  rows m 0..31 first; da1 of tile 1 under them ----
-    phasewg<16>(Pa[0][0], Pa[0][1], imrow(imA, 0), imrow(imA, 0), imrow(imZ, 0), imrow(imZ, 32),
-                [&](int u) { if (u >= 2 && u < 18) da1_chunk(1, u - 2); });
-    float s3 = 0.f;
-    phasewg<16>(Pa[1][0], Pa[1][1], imrow(imA, 32), imrow(imA, 32), imrow(imZ, 0), imrow(imZ, 32),
-                [&](int u) { if (!(ABL & 4)) s3 += bufA[u * LDB + lane]; });
-    cs_da1 += s3;
-    // ---- P7  dz^T = A^T da1^T tile by tile (atomics deferred to the next row tile) ----
-    auto w_p7 = [&](int t) { return [=](int s) { return pA_c[(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * LW + 32 * t]; }; };
-    auto b_d = [&](int s) { return dacc[s >> 4][s & 15]; };
-    dzp_prev = a.dzT + (int64_t)(4 * hh) * a.N + n;
-    phase1<32, true>(zacc[0], w_p7(0), b_d, none);
-    phase1<32, true>(zacc[1], w_p7(1), b_d, none);
-    n = n_next;
-    live = live_next;
-  }
-  if (had_tiles && !(ABL & 1)) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) atomicAdd(dzp_prev + (int64_t)(32 * t + OIVAE_ROWC(r)) * a.N, zacc[t][r]);
-  }
-
-  // ---- reduce the four waves' partials in a fixed order ----
-  const int64_t cs = a.chunk_stride * chunk;
-  float* stage = sAct;  // 4 x 4096 floats
-  auto stage_acc = [&](f32x16 (&acc)[2][2]) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          stage[wave * 4096 + (32 * i + OIVAE_ROW(r, hh)) * 64 + 32 * j + l31] = acc[i][j][r];
-    __syncthreads();
-  };
-  stage_acc(dW2a);
-  {
-    float* dst = a.gW2 + cs + (int64_t)g * DG * M;
-    for (int idx = tid; idx < 4096; idx += 256)
-      dst[idx] = ((stage[idx] + stage[4096 + idx]) + stage[2 * 4096 + idx]) + stage[3 * 4096 + idx];
-  }
-  stage_acc(Pa);
-  // P -> sA's place, W1 -> sW2's place, Ws behind the staging area (all stride LW)
-  float* sP = sA;
-  float* uW1 = sW2;
-  float* uWs = sAct + 4 * 4096;
-  for (int idx = tid; idx < 4096; idx += 256) {
-    const int o = (idx >> 6) * LW + (idx & 63);
-    sP[o] = ((stage[idx] + stage[4096 + idx]) + stage[2 * 4096 + idx]) + stage[3 * 4096 + idx];
-    uW1[o] = W1g[idx];
-    uWs[o] = Wsg[idx];
-  }
-  __syncthreads();
-  {
-    const int it = wave >> 1, ht = wave & 1;
-    // dW1[m][h] = sum_k P[m][k] Ws[k][h]
-    f32x16 acc = (f32x16)(0.f);
-    const float* pa = sP + (32 * it + l31) * LW + hh;
-    const float* pb = uWs + hh * LW + 32 * ht + l31;
-#pragma unroll 8
-    for (int s = 0; s < 32; ++s) acc = mf32(pa[2 * s], pb[2 * s * LW], acc);
-    float* d1 = a.gW1 + cs + (int64_t)g * M * H;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) d1[(32 * it + OIVAE_ROW(r, hh)) * H + 32 * ht + l31] = acc[r];
-    // dWs[k][h] = sum_m P[m][k] W1[m][h]
-    acc = (f32x16)(0.f);
-    pa = sP + hh * LW + 32 * it + l31;
-    pb = uW1 + hh * LW + 32 * ht + l31;
-#pragma unroll 8
-    for (int s = 0; s < 32; ++s) acc = mf32(pa[2 * s * LW], pb[2 * s * LW], acc);
-    float* d2 = a.gWs + cs + (int64_t)g * K * H;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) d2[(32 * it + OIVAE_ROW(r, hh)) * H + 32 * ht + l31] = acc[r];
-  }
-  stage[wave * 192 + lane] = cs_gmu;          // stage[0, 768) is free again: the sums above read the other areas
-  stage[wave * 192 + 64 + lane] = cs_gmu2;
-  stage[wave * 192 + 128 + lane] = cs_da1;
-  __syncthreads();
-  float* sred = stage + 1024;
-  if (tid < 64) {
-    const float s_gmu = ((stage[tid] + stage[192 + tid]) + stage[384 + tid]) + stage[576 + tid];
-    const float s_gmu2 = ((stage[64 + tid] + stage[256 + tid]) + stage[448 + tid]) + stage[640 + tid];
-    const float s_da1 = ((stage[128 + tid] + stage[320 + tid]) + stage[512 + tid]) + stage[704 + tid];
-    const int64_t d = (int64_t)g * DG + tid;
-    const float e = expf(a.ls[d]);
-    const float sg = e + a.sig_off;
-    const float c2 = a.inv / sg;
-    const float sumq2 = s_gmu2 / (c2 * c2);  // gmu = -q * inv/sigma with q = (x - mu)/sigma
-    const float nrows = (chunk == 0) ? (float)a.N : 0.f;
-    a.gb2[cs + d] = s_gmu;
-    a.gls[cs + d] = (nrows - sumq2) * (e * a.inv / sg);
-    a.gb1[cs + (int64_t)g * M + tid] = s_da1;
-    sred[tid] = nrows * (-0.5f * kLog2Pi - logf(sg)) - 0.5f * sumq2;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double tot = 0.0;
-    for (int i = 0; i < 64; ++i) tot += (double)sred[i];
-    a.ll_part[(int64_t)chunk * gridDim.x + g] = tot;
-  }
-}
-
 
 // ==============================================================================
 // v4 of the all-64 kernel: v3's six-product data flow with the instruction stream
@@ -1558,48 +944,14 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   a.sig_off = gen_sig_off;
   a.ll_part = w.ll_part;
   int rc;
-  const char* ver = getenv("OIVAE_DEC");  // test hook: "v1" | "v2" | "v3" select the older all-64 kernels
-  if (s.K == 64 && !ver && N * (int64_t)s.K * 4 < (int64_t)1 << 32) {
+  // OIVAE_DEC=v1 (test hook) selects the layer-by-layer template kernel for the all-64 shape, which also serves
+  // launches whose dz image exceeds the 32-bit byte offsets of dec_mfma64_v4's atomics (N*K*4 >= 2^32)
+  const bool force_v1 = getenv("OIVAE_DEC") != nullptr;
+  if (s.K == 64 && !force_v1 && N * (int64_t)s.K * 4 < (int64_t)1 << 32) {
     const size_t lds = (size_t)(3 * 64 * 65 + 4 * 64 + 4 * 3 * 32 * 68) * sizeof(float);
     OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_mfma64_v4),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(dec_mfma64_v4, dim3((unsigned)s.G, (unsigned)chunks), dim3(256), lds, st, a);
-    OIVAE_LAUNCH_CHECK();
-    rc = OIVAE_OK;
-  } else if (s.K == 64 && (!ver || (ver[0] == 'v' && ver[1] == '3'))) {
-    const size_t lds = (size_t)(2 * 64 * 65 + 4 * 64 + 4 * 3 * 32 * 68) * sizeof(float);
-    rc = OIVAE_OK;
-#define OIVAE_V3_LAUNCH(ABL)                                                                             \
-  {                                                                                                      \
-    OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_mfma64_v3<ABL>),               \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
-    hipLaunchKernelGGL(dec_mfma64_v3<ABL>, dim3((unsigned)s.G, (unsigned)chunks), dim3(256), lds, st, a); \
-  }
-#ifdef OIVAE_DIAG_VARIANTS
-    const char* ab = getenv("OIVAE_DEC_ABLATE");
-    const int abl = ab ? atoi(ab) : 0;
-    switch (abl) {
-      case 0: OIVAE_V3_LAUNCH(0) break;
-      case 1: OIVAE_V3_LAUNCH(1) break;
-      case 2: OIVAE_V3_LAUNCH(2) break;
-      case 4: OIVAE_V3_LAUNCH(4) break;
-      case 8: OIVAE_V3_LAUNCH(8) break;
-      case 16: OIVAE_V3_LAUNCH(16) break;
-      case 32: OIVAE_V3_LAUNCH(32) break;
-      case 64: OIVAE_V3_LAUNCH(64) break;
-      case 127: OIVAE_V3_LAUNCH(127) break;
-      default: return fail(OIVAE_E_ARG, "unknown OIVAE_DEC_ABLATE=%d", abl);
-    }
-#else
-    OIVAE_V3_LAUNCH(0)
-#endif
-#undef OIVAE_V3_LAUNCH
-    OIVAE_LAUNCH_CHECK();
-  } else if (s.K == 64 && ver[0] == 'v' && ver[1] == '2') {
-    const size_t lds = (size_t)(3 * 64 * 65 + 64 + 3 * 64 + 4 * 2 * 32 * 68) * sizeof(float);
-    OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_mfma64_v2),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(dec_mfma64_v2, dim3((unsigned)s.G, (unsigned)chunks), dim3(256), lds, st, a);
     OIVAE_LAUNCH_CHECK();
     rc = OIVAE_OK;
   } else if (s.K == 64) rc = launch_one<64, 64, 64, 64>(a, s.G, chunks, st);

@@ -52,25 +52,27 @@ def test_mfma_kernels_agree_with_generic_kernels(tmp_path):
   script = tmp_path / "cross.py"
   script.write_text(_CROSS % {"root": ROOT})
   res = {}
-  for mode in ("mfma", "generic"):
+  for mode in ("mfma", "generic", "layerwise"):
     env = dict(os.environ)
     if mode == "generic":
       env["OIVAE_FORCE_GENERIC"] = "1"
+    if mode == "layerwise":
+      env["OIVAE_DEC"] = "v1"   # the nine-product template kernel instead of the composed-first-layer one
     out = tmp_path / (mode + ".npz")
     subprocess.run([sys.executable, str(script), mode, str(out)], check=True, env=env, timeout=300)
     res[mode] = np.load(out)
-  a, b = res["mfma"], res["generic"]
-  assert np.max(np.abs(a["sc"][:6] - b["sc"][:6]) / np.maximum(np.abs(b["sc"][:6]), 1)) < 1e-5
-  assert np.array_equal(a["z"], b["z"]) or np.max(np.abs(a["z"] - b["z"])) < 1e-5
-  from oi_vae_amd import Engine  # segment-wise comparison relative to each tensor's scale
-  eng = _engine(24, 64, 64, 64, 64, seed=1)
-  for name in eng.seg_off:
-    o, n = eng.seg_off[name], eng.seg_numel[name]
-    if n == 0:
-      continue
-    ga, gb = a["grads"][o:o + n], b["grads"][o:o + n]
-    err = np.max(np.abs(ga - gb)) / max(np.max(np.abs(gb)), 1e-30)
-    assert err < 2e-5, (name, err)
+  eng = _engine(24, 64, 64, 64, 64, seed=1)  # segment-wise comparison relative to each tensor's scale
+  for other in ("generic", "layerwise"):
+    a, b = res["mfma"], res[other]
+    assert np.max(np.abs(a["sc"][:6] - b["sc"][:6]) / np.maximum(np.abs(b["sc"][:6]), 1)) < 1e-5, other
+    assert np.array_equal(a["z"], b["z"]) or np.max(np.abs(a["z"] - b["z"])) < 1e-5
+    for name in eng.seg_off:
+      o, n = eng.seg_off[name], eng.seg_numel[name]
+      if n == 0:
+        continue
+      ga, gb = a["grads"][o:o + n], b["grads"][o:o + n]
+      err = np.max(np.abs(ga - gb)) / max(np.max(np.abs(gb)), 1e-30)
+      assert err < 2e-5, (other, name, err)
 
 
 def test_full_scale_batch_equals_mean_of_half_batches():
