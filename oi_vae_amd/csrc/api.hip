@@ -75,10 +75,19 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
     off += align_up(nbytes, 256);
     return r;
   };
-  w->n_kl = kMaxPartials;
-  w->kl_part = reinterpret_cast<double*>(take(sizeof(double) * kMaxPartials));
-  w->n_ll = kMaxPartials;
+  // every slot below n_* is written by exactly one block of its producer kernel on every step (no memset needed)
+  {
+    int64_t eb = (B * s.K + 255) / 256;
+    w->n_kl = (int32_t)(eb > kEncEpiBlocks ? kEncEpiBlocks : eb);
+  }
+  w->kl_part = reinterpret_cast<double*>(take(sizeof(double) * kEncEpiBlocks));
+  w->n_ll = s.G * plan.chunks;
   w->ll_part = reinterpret_cast<double*>(take(sizeof(double) * kMaxPartials));
+  {
+    int64_t bb = (B + 63) / 64;  // at least 64 rows per block
+    w->n_bias = (int32_t)(bb > kBiasBlocks ? kBiasBlocks : bb);
+  }
+  w->bias_part = reinterpret_cast<double*>(take(sizeof(double) * kBiasBlocks * 2 * s.K));
   w->n_theta = 1024;
   w->theta_part = reinterpret_cast<double*>(take(sizeof(double) * 1024));
   w->n_pen = 1024;

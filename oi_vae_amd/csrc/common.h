@@ -42,12 +42,15 @@ struct Workspace {
   double* pen_part;     int32_t n_pen;     // penalty partials
   float*  dpre;                            // [enc_splits, B, 2K] pre-activation partials (fwd), then [B, 2K] their grads (bwd)
   int32_t enc_splits;
+  double* bias_part;    int32_t n_bias;    // [n_bias, 2K] per-block column sums of dpre (encoder bias gradients)
   float*  slab;         int32_t n_chunks;  // [n_chunks, P_dec] decoder grad partials (n_chunks > 1)
   int64_t p_dec;                           // floats per decoder-grad slab
   int64_t total_bytes;
 };
 
 constexpr int kMaxPartials = 16384;
+constexpr int kEncEpiBlocks = 2048;  // cap on enc_fwd_epilogue blocks (= KL partials)
+constexpr int kBiasBlocks = 256;     // cap on enc_bwd_pre blocks (= bias-gradient partials)
 constexpr int kMaxEncSplits = 8;     // split-K partial images of the encoder pre-activations  // cap on per-kernel block counts that emit partials
 
 // sizes of the decoder parameter block, in floats, in slab order:

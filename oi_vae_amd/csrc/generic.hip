@@ -344,7 +344,9 @@ void launch_slab_reduce(const float* slab, int64_t P, int chunks, float* dst, in
 // encoder backward (lib/oivae.py:75, encoder half)
 // ------------------------------------------------------------------------------
 // dz element (n, k) lives at dz[n*dz_sn + k*dz_sk]: [N,K] from the generic decoder,
-// [K,N] from the MFMA decoder
+// [K,N] from the MFMA decoder.
+// One block owns a contiguous slab of rows: it writes dpre [B, 2K] for them and the slab's column sums
+// (the encoder bias gradients' partials, summed over blocks in index order by enc_bwd_bias_final).
 __global__ __launch_bounds__(256) void enc_bwd_pre(int64_t B, int K, int S, const float* __restrict__ dz,
                                                    int64_t dz_sn, int64_t dz_sk,
                                                    const float* __restrict__ eps, float c,
@@ -352,12 +354,20 @@ __global__ __launch_bounds__(256) void enc_bwd_pre(int64_t B, int K, int S, cons
                                                    const float* __restrict__ prior_sigma, int prior_stride,
                                                    const float* __restrict__ mu_q,
                                                    const float* __restrict__ sig_q,
-                                                   const float* __restrict__ ea, float* __restrict__ dpre) {
-  const int64_t total = B * K;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+                                                   const float* __restrict__ ea, float* __restrict__ dpre,
+                                                   double* __restrict__ bias_part) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* col = reinterpret_cast<double*>(smem_raw);  // [2K] column sums of this block
+  const int tid = threadIdx.x;
+  for (int j = tid; j < 2 * K; j += 256) col[j] = 0.0;
+  __syncthreads();
+  const int64_t rpb = (B + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  const int64_t r1 = (r0 + rpb < B) ? r0 + rpb : B;
   const float invB = 1.0f / (float)B;
-  for (; i < total; i += stride) {
+  const bool fixed_col = (256 % K) == 0;  // then thread t always meets column t % K: sums stay in registers
+  double smu = 0.0, sda = 0.0;
+  for (int64_t i = r0 * K + tid; i < r1 * K; i += 256) {
     const int64_t b = i / K;
     const int k = (int)(i - b * K);
     float sdz = 0.f, sdze = 0.f;
@@ -371,22 +381,36 @@ __global__ __launch_bounds__(256) void enc_bwd_pre(int64_t B, int K, int S, cons
     const float sq = sig_q[i];
     const float dmu = sdz + ((mu_q[i] - mp) / (sp * sp)) * invB;
     const float dsig = sdze + (sq / (sp * sp) - 1.0f / sq) * invB;
+    const float da = dsig * c * ea[i];
     dpre[b * 2 * K + k] = dmu;
-    dpre[b * 2 * K + K + k] = dsig * c * ea[i];
+    dpre[b * 2 * K + K + k] = da;
+    if (fixed_col) { smu += (double)dmu; sda += (double)da; }
+    else { atomicAdd(&col[k], (double)dmu); atomicAdd(&col[K + k], (double)da); }  // LDS; odd K only (order-dependent in the last bits)
   }
+  if (fixed_col) {
+    // threads t, t+K, t+2K, ... hold the same column: fold them in a fixed order
+    double* sm = col + 2 * K;  // [2][256]
+    sm[tid] = smu;
+    sm[256 + tid] = sda;
+    __syncthreads();
+    if (tid < K) {
+      double a = 0.0, d = 0.0;
+      for (int j = tid; j < 256; j += K) { a += sm[j]; d += sm[256 + j]; }
+      col[tid] = a;
+      col[K + tid] = d;
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < 2 * K; j += 256) bias_part[(int64_t)blockIdx.x * 2 * K + j] = col[j];
 }
 
-// one block per column j of dpre [B, J]: bias gradients
-__global__ __launch_bounds__(256) void enc_bwd_bias(const float* __restrict__ dpre, int64_t B, int K,
-                                                    float* __restrict__ dbmu, float* __restrict__ dbsig) {
-  __shared__ double sred[256];
-  const int j = blockIdx.x, J = 2 * K;
+__global__ __launch_bounds__(256) void enc_bwd_bias_final(const double* __restrict__ bias_part, int nblk, int K,
+                                                          float* __restrict__ dbmu, float* __restrict__ dbsig) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= 2 * K) return;
   double acc = 0.0;
-  for (int64_t b = threadIdx.x; b < B; b += 256) acc += (double)dpre[b * J + j];
-  const double tot = block_sum_double(acc, sred);
-  if (threadIdx.x == 0) {
-    if (j < K) dbmu[j] = (float)tot; else dbsig[j - K] = (float)tot;
-  }
+  for (int b = 0; b < nblk; ++b) acc += bias_part[(int64_t)b * 2 * K + j];
+  if (j < K) dbmu[j] = (float)acc; else dbsig[j - K] = (float)acc;
 }
 
 // dW[j][d] = sum_b dpre[b][j] X[b][d]; block = 32 j x 64 d, loops over all b in order
@@ -512,9 +536,7 @@ extern "C" int oivae_encoder_fwd_f32(const oivae_shape_t* shape, const oivae_ten
                        params->enc_Wmu, params->enc_Wsig, pre);
     OIVAE_LAUNCH_CHECK();
   }
-  OIVAE_HIP_CHECK(hipMemsetAsync(w.kl_part, 0, sizeof(double) * w.n_kl, st));
-  int64_t eblocks = (B * shape->K + 255) / 256;
-  if (eblocks > 2048) eblocks = 2048;
+  const int64_t eblocks = w.n_kl;  // every block writes its KL partial
   hipLaunchKernelGGL(enc_fwd_epilogue, dim3((unsigned)eblocks), dim3(256), 0, st, pre, w.enc_splits, B, shape->K,
                      params->enc_bmu, params->enc_bsig, S, eps, c, sig_off, prior_mu, prior_sigma,
                      prior_rows == 1 ? 0 : shape->K, mu_q, sig_q, ea, z, w.kl_part);
@@ -536,7 +558,6 @@ extern "C" int oivae_decoder_fwd_bwd_f32(const oivae_shape_t* shape, const oivae
   hipStream_t st = (hipStream_t)stream;
   const int64_t N = B * (int64_t)S;
   const DecPlan pl = plan_decoder(s, N);
-  OIVAE_HIP_CHECK(hipMemsetAsync(w.ll_part, 0, sizeof(double) * w.n_ll, st));
   OIVAE_HIP_CHECK(hipMemsetAsync(dz, 0, sizeof(float) * N * s.K, st));
   if (pl.mfma) return launch_decoder_mfma(s, params, grads, X, B, S, z, gen_sig_off, dz, w, st);
   if (pl.R == 0)
@@ -615,15 +636,14 @@ extern "C" int oivae_encoder_bwd_f32(const oivae_shape_t* shape, const oivae_ten
   Workspace w;
   if (int rc = carve_workspace(s, B, S, workspace, workspace_bytes, &w)) return rc;
   hipStream_t st = (hipStream_t)stream;
-  int64_t blocks = (B * s.K + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
   const bool dz_transposed = plan_decoder(s, B * (int64_t)S).mfma;
   const int64_t dz_sn = dz_transposed ? 1 : s.K, dz_sk = dz_transposed ? B * (int64_t)S : 1;
-  hipLaunchKernelGGL(enc_bwd_pre, dim3((unsigned)blocks), dim3(256), 0, st, B, s.K, S, dz, dz_sn, dz_sk, eps, c, prior_mu,
-                     prior_sigma, prior_rows == 1 ? 0 : s.K, mu_q, sig_q, ea, w.dpre);
+  const size_t pre_lds = sizeof(double) * (2 * (size_t)s.K + 512);
+  hipLaunchKernelGGL(enc_bwd_pre, dim3((unsigned)w.n_bias), dim3(256), pre_lds, st, B, s.K, S, dz, dz_sn, dz_sk, eps, c,
+                     prior_mu, prior_sigma, prior_rows == 1 ? 0 : s.K, mu_q, sig_q, ea, w.dpre, w.bias_part);
   OIVAE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(enc_bwd_bias, dim3((unsigned)(2 * s.K)), dim3(256), 0, st, w.dpre, B, s.K, grads->enc_bmu,
-                     grads->enc_bsig);
+  hipLaunchKernelGGL(enc_bwd_bias_final, dim3((unsigned)((2 * s.K + 255) / 256)), dim3(256), 0, st, w.bias_part, w.n_bias,
+                     s.K, grads->enc_bmu, grads->enc_bsig);
   OIVAE_LAUNCH_CHECK();
   if (mfma_encoder_applies(s)) {
     if (int rc = launch_encoder_bwd_mfma(s, grads, X, w.dpre, B, st)) return rc;

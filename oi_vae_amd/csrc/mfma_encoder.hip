@@ -242,7 +242,9 @@ struct FwdPlan { int cfg; int splits; };
 static FwdPlan plan_fwd(const oivae_shape_t& s, int64_t B) {
   const int J = 2 * s.K;
   FwdPlan p;
-  const bool big = B >= 256 * 192;
+  // 256-row tiles whenever split-K (at most kMaxEncSplits slices of D) can still put >= 256 workgroups on the chip:
+  // they issue 128 MFMAs per wave per barrier and re-read the weights B/256 times instead of B/64
+  const bool big = B >= 256 * (256 / kMaxEncSplits);
   int bm, bn;
   if (J % 128 == 0) { p.cfg = big ? 0 : 1; bm = big ? 256 : 64; bn = 128; }
   else if (J % 64 == 0) { p.cfg = big ? 2 : 3; bm = big ? 256 : 64; bn = 64; }
