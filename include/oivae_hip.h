@@ -105,6 +105,17 @@ int oivae_sgd_prox_f32(float* Ws, const float* dWs, int64_t rows, int32_t H,
                        float lr, float t, int32_t do_prox,
                        uint8_t* zero_mask, float* row_norms, void* stream);
 
+/* Column form of the proximal step: replaces FirstLayerSparseDecoder.proximal_step,
+ * lib/models.py:65-71 (the autoencoder variant's decoder, data_vs_test_loss_autoencoder.py:126).
+ * W holds the G latent-to-group maps stacked on rows, [sum_g H_g, K] (each map is the
+ * nn.Linear(K, H_g, bias=False).weight of lib/models.py:41-44); group_off is a DEVICE array of
+ * G+1 int32 prefix sums of H_g; max_group_rows the largest H_g.  In place, for every map g and
+ * column k:  n = sqrt(sum_h W_g[h,k]^2); W_g[:,k] = (W_g[:,k] / max(n,1e-16)) * max(n - t, 0),
+ * bit for bit as the reference's CPU path (torch's column-sum order over dim 0, MKL-VML root).
+ * zero_mask / col_norms (optional): [G, K]. */
+int oivae_prox_cols_f32(float* W, const int32_t* group_off, int32_t G, int32_t K, int32_t max_group_rows,
+                        float t, uint8_t* zero_mask, float* col_norms, void* stream);
+
 /* ---- encoder forward + reparameterisation + KL ---------------------------
  * Replaces inference_model(X) (lib/models.py:15-16 with the heads of
  * bars_data_oivae.py:66-87), KL_Normals (lib/utils.py:9-18, lib/oivae.py:50)

@@ -9,7 +9,7 @@ executed by hand-written gfx950 HIP kernels behind a C ABI
 from ._lib import OivaeError  # noqa: F401
 from .engine import Engine, ModelSpec  # noqa: F401
 from .distributions import DistributionCat, Normal  # noqa: F401
-from .models import BayesianGroupLassoGenerator, NormalNet  # noqa: F401
+from .models import BayesianGroupLassoGenerator, FirstLayerSparseDecoder, NormalNet  # noqa: F401
 from .oivae import OIVAE, NormalPriorTheta  # noqa: F401
 from .utils import KL_Normals, Lambda  # noqa: F401
 from . import optim, parallel  # noqa: F401

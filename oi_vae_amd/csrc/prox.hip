@@ -200,6 +200,87 @@ __global__ __launch_bounds__(256) void prox_rows_vec(float* __restrict__ Ws,
   }
 }
 
+// ---- column form: FirstLayerSparseDecoder.proximal_step (/root/reference/lib/models.py:65-71) ----
+// The G latent-to-group maps (nn.Linear(K, H_g).weight, [H_g, K]) are stacked on rows; a column of one map
+// is soft-thresholded by its norm over dim 0.  One thread per (map, column): consecutive threads read
+// consecutive k, so every row of a map is one coalesced access.  The sum order is torch 2.10's CPU
+// outer-reduction kernel, restated rule by rule in oracle/prox_oracle.c (multi_row_sumsq / row_sum_sumsq).
+__device__ __forceinline__ float cols_multi_row(const float* __restrict__ w, int64_t stride, int n) {
+  float a0 = 0.0f, a1 = 0.0f;
+  int i = 0;
+  while (i + 16 <= n) {
+    for (int j = 0; j < 16; ++j, ++i) { const float v = w[(int64_t)i * stride]; a0 = a0 + v * v; }
+    a1 = a1 + a0;
+    a0 = 0.0f;
+  }
+  for (; i < n; ++i) { const float v = w[(int64_t)i * stride]; a0 = a0 + v * v; }
+  a0 = a0 + a1;
+  return a0;
+}
+
+__global__ __launch_bounds__(256) void prox_cols(float* __restrict__ W, const int32_t* __restrict__ group_off,
+                                                 int G, int K, float t, uint8_t* __restrict__ mask,
+                                                 float* __restrict__ norms, const uint16_t* __restrict__ tab) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)G * K) return;
+  const int g = (int)(idx / K), k = (int)(idx - (int64_t)g * K);
+  const int r0 = group_off[g], H = group_off[g + 1] - r0;
+  float* w = W + (int64_t)r0 * K + k;
+  float acc;
+  if (K == 1) {
+    // contiguous inner reduction: the row kernel's order (8-lane vectors, 4 interleaved accumulators)
+    if (H < 8) {
+      float p[4] = {0.f, 0.f, 0.f, 0.f};
+      const int nq = H / 4;
+      for (int i = 0; i < nq; ++i)
+        for (int q = 0; q < 4; ++q) { const float v = w[4 * i + q]; p[q] = p[q] + v * v; }
+      for (int i = nq * 4; i < H; ++i) { const float v = w[i]; p[0] = p[0] + v * v; }
+      p[0] = p[0] + p[1]; p[0] = p[0] + p[2]; p[0] = p[0] + p[3];
+      acc = p[0];
+    } else {
+      float P[4][8];
+      for (int q = 0; q < 4; ++q)
+        for (int l = 0; l < 8; ++l) P[q][l] = 0.f;
+      const int V = H / 8, nq = V / 4;
+      for (int i = 0; i < nq; ++i)
+        for (int q = 0; q < 4; ++q)
+          for (int l = 0; l < 8; ++l) { const float v = w[(4 * i + q) * 8 + l]; P[q][l] = P[q][l] + v * v; }
+      for (int i = nq * 4; i < V; ++i)
+        for (int l = 0; l < 8; ++l) { const float v = w[i * 8 + l]; P[0][l] = P[0][l] + v * v; }
+      for (int q = 1; q < 4; ++q)
+        for (int l = 0; l < 8; ++l) P[0][l] = P[0][l] + P[q][l];
+      acc = 0.f;
+      for (int i = V * 8; i < H; ++i) { const float v = w[i]; acc = acc + v * v; }
+      for (int l = 0; l < 8; ++l) acc = acc + P[0][l];
+    }
+  } else {
+    const int n_seq = (K >= 8) ? (K / 32) * 32 : (K / 4) * 4;
+    if (k < n_seq) {
+      acc = cols_multi_row(w, K, H);
+    } else {
+      const int n4 = H / 4;
+      float p[4];
+      for (int q = 0; q < 4; ++q) p[q] = cols_multi_row(w + (int64_t)q * K, 4 * (int64_t)K, n4);
+      for (int i = 4 * n4; i < H; ++i) { const float v = w[(int64_t)i * K]; p[0] = p[0] + v * v; }
+      p[0] = p[0] + p[1]; p[0] = p[0] + p[2]; p[0] = p[0] + p[3];
+      acc = p[0];
+    }
+  }
+  const float n = mkl_sqrtf_dev(acc, tab);
+  float den, sc;
+  prox_scales(n, t, den, sc);
+  bool allzero = true;
+  for (int h = 0; h < H; ++h) {
+    float v = w[(int64_t)h * K];
+    v = v / den;
+    v = v * sc;
+    w[(int64_t)h * K] = v;
+    allzero = allzero && (v == 0.0f);
+  }
+  if (mask) mask[idx] = allzero ? 1 : 0;
+  if (norms) norms[idx] = n;
+}
+
 template <bool SGD>
 static int launch_prox(float* Ws, const float* dWs, int64_t rows, int H, float lr, float t,
                        int do_prox, uint8_t* mask, float* norms, hipStream_t st) {
@@ -252,4 +333,20 @@ extern "C" int oivae_sgd_prox_f32(float* Ws, const float* dWs, int64_t rows, int
     return fail(OIVAE_E_SHAPE, "oivae_sgd_prox_f32: H=%d outside [1,512)", H);
   if (rows * 2 / 256 > 0x7fffffffLL) return fail(OIVAE_E_SHAPE, "oivae_sgd_prox_f32: too many rows");
   return launch_prox<true>(Ws, dWs, rows, H, lr, t, do_prox ? 1 : 0, zero_mask, row_norms, (hipStream_t)stream);
+}
+
+extern "C" int oivae_prox_cols_f32(float* W, const int32_t* group_off, int32_t G, int32_t K, int32_t max_group_rows,
+                                   float t, uint8_t* zero_mask, float* col_norms, void* stream) {
+  if (!W || !group_off || G < 0 || K < 1) return fail(OIVAE_E_ARG, "oivae_prox_cols_f32: null pointer or bad sizes");
+  if (max_group_rows < 1 || max_group_rows >= 512 || (int64_t)max_group_rows * K >= 32768)
+    return fail(OIVAE_E_SHAPE, "oivae_prox_cols_f32: H_g=%d, K=%d outside the range where the reference's column-sum "
+                               "order is pinned (H_g < 512, H_g*K < 32768)", max_group_rows, K);
+  const uint16_t* tab = rsqrt14_table_device();
+  if (!tab) return fail(OIVAE_E_NOINIT, "oivae_init has not been called on this device");
+  if (G == 0) return OIVAE_OK;
+  const int64_t n = (int64_t)G * K;
+  hipLaunchKernelGGL(prox_cols, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, group_off, G, K, t,
+                     zero_mask, col_norms, tab);
+  OIVAE_LAUNCH_CHECK();
+  return OIVAE_OK;
 }

@@ -31,6 +31,97 @@ class NormalNet(object):
     self.sigma_net.cuda()
 
 
+class FirstLayerSparseDecoder(object):
+  """Group-lasso sparse first layer for plain autoencoders, with the reference's
+  interface (lib/models.py:29-71; driver data_vs_test_loss_autoencoder.py:31-50,
+  96-145).  Forward and backward of this variant are ordinary torch modules (the
+  reference trains it with autograd); the proximal step -- the operation the two
+  decoder classes share -- runs in the HIP kernel `oivae_prox_cols_f32`, bit-identical
+  to the reference's CPU arithmetic.  On the first GPU proximal step the G map weights
+  are packed into one [sum H_g, K] device buffer (each nn.Linear weight becomes a view of
+  it, so optimizers keep their Parameter objects) and one launch serves all maps."""
+
+  def __init__(self, group_generators, group_generators_input_dims, input_dim):
+    assert len(group_generators) == len(group_generators_input_dims)
+    self.group_generators = group_generators
+    self.group_generators_input_dims = group_generators_input_dims
+    self.input_dim = input_dim
+    self.latent_to_group_maps = [
+      torch.nn.Linear(self.input_dim, k, bias=False)
+      for k in self.group_generators_input_dims
+    ]
+    self._flat = None
+    self._group_off = None
+    self.zero_mask = None
+    self.col_norms = None
+
+  def __call__(self, z):
+    return torch.cat(
+      [gen(m(z)) for gen, m in zip(self.group_generators, self.latent_to_group_maps)],
+      dim=-1)
+
+  def parameters(self):
+    return itertools.chain(
+      *[gen.parameters() for gen in self.group_generators],
+      *[m.parameters() for m in self.latent_to_group_maps])
+
+  def group_lasso_penalty(self):
+    return sum([
+      torch.sum(torch.sqrt(torch.sum(torch.pow(m.weight, 2), dim=0)))
+      for m in self.latent_to_group_maps])
+
+  def cuda(self):
+    for gen in self.group_generators:
+      gen.cuda()
+    for m in self.latent_to_group_maps:
+      m.cuda()
+    self._flat = None
+    return self
+
+  def _packed(self):
+    maps = self.latent_to_group_maps
+    dev = maps[0].weight.device
+    if dev.type != "cuda":
+      raise _lib.OivaeError("proximal_step runs on the GPU: call .cuda() on the decoder first (there is no CPU fallback)")
+    K = self.input_dim
+    ok = self._flat is not None and self._flat.device == dev
+    if ok:
+      off = 0
+      for m in maps:  # still views of the packed buffer?
+        h = m.weight.shape[0]
+        ok = ok and m.weight.data_ptr() == self._flat.data_ptr() + off * K * 4 and m.weight.is_contiguous()
+        off += h
+    if not ok:
+      dims = [int(m.weight.shape[0]) for m in maps]
+      flat = torch.empty(sum(dims), K, dtype=torch.float32, device=dev)
+      off = 0
+      for m, h in zip(maps, dims):
+        flat[off:off + h].copy_(m.weight.data)
+        m.weight.data = flat[off:off + h]
+        off += h
+      self._flat = flat
+      self._dims = dims
+      self._group_off = torch.tensor([0] + list(itertools.accumulate(dims)), dtype=torch.int32, device=dev)
+      self.zero_mask = torch.zeros(len(dims), K, dtype=torch.uint8, device=dev)
+      self.col_norms = torch.zeros(len(dims), K, dtype=torch.float32, device=dev)
+    return self._flat
+
+  def proximal_step(self, t):
+    """Block soft-threshold of every column of every map in place (lib/models.py:65-71)."""
+    flat = self._packed()
+    dev = flat.device
+    L = _lib.init_device(dev.index)
+    with torch.cuda.device(dev):
+      st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+      _lib.check(L.oivae_prox_cols_f32(flat.data_ptr(), self._group_off.data_ptr(), len(self._dims), self.input_dim,
+                                       max(self._dims), float(t), self.zero_mask.data_ptr(),
+                                       self.col_norms.data_ptr(), st), "oivae_prox_cols_f32")
+
+  def connectivity(self):
+    """[G, K] matrix of column norms ||W_g[:, k]|| (latent k -> group g)."""
+    return torch.stack([torch.sqrt(torch.sum(torch.pow(m.weight.data, 2), dim=0)) for m in self.latent_to_group_maps])
+
+
 class BayesianGroupLassoGenerator(object):
   """Group-lasso sparse first layer `Ws` [G, K, H] followed by one generator
   net per group (lib/models.py:73-119)."""

@@ -126,3 +126,84 @@ int oivae_oracle_prox_f32(float* Ws, long rows, int H, float t, const uint16_t* 
   }
   return 0;
 }
+
+/* ---------------------------------------------------------------------------
+ * FirstLayerSparseDecoder.proximal_step, /root/reference/lib/models.py:65-71:
+ * per latent-to-group map W_g [H_g, K] (nn.Linear(K, H_g).weight):
+ *     n = sqrt(sum(pow(W_g, 2), dim=0));  W_g /= clamp(n, 1e-16);  W_g *= clamp(n - t, 0)
+ * The column sum over dim 0 follows torch 2.10's CPU outer-reduction kernel
+ * (aten SumKernel: vectorized_outer_sum / scalar_outer_sum), probed in the build
+ * container and pinned by tests/golden/fls_prox_vectors.npz:
+ *   - columns are handled in chunks of 32 (4 vectors of 8) while 32 remain -- for
+ *     K < 8 in chunks of 4 -- by multi_row_sum: rows added in order into one
+ *     accumulator per column, flushed into a second-level accumulator every 16 rows;
+ *   - the remaining columns by row_sum: four interleaved accumulators over rows
+ *     (row r -> accumulator r mod 4, each a multi_row_sum over H/4 terms), leftover
+ *     rows into accumulator 0, then accumulators 1..3 added in order;
+ *   - K == 1 is a contiguous inner reduction: the order of oivae_oracle_row_sumsq.
+ * Pinned for H_g < 512 and H_g*K < 32768 (single-threaded reduction, one cascade level).
+ * ------------------------------------------------------------------------- */
+static float multi_row_sumsq(const float* w, long stride, int n) {
+  /* level step 16 for n < 2^20; with n < 512 at most two levels are ever non-zero */
+  float a0 = 0.0f, a1 = 0.0f;
+  int i = 0;
+  while (i + 16 <= n) {
+    for (int j = 0; j < 16; j++, i++) { float v = w[(long)i * stride]; a0 = a0 + v * v; }
+    a1 = a1 + a0;
+    a0 = 0.0f;
+  }
+  for (; i < n; i++) { float v = w[(long)i * stride]; a0 = a0 + v * v; }
+  a0 = a0 + a1;
+  a0 = a0 + 0.0f; /* levels 2 and 3 are zero; +0 keeps the bits (a0 is never -0: sums of squares) */
+  return a0;
+}
+
+static float row_sum_sumsq(const float* w, long stride, int n) {
+  int n4 = n / 4;
+  float p[4];
+  for (int k = 0; k < 4; k++) p[k] = multi_row_sumsq(w + (long)k * stride, 4 * stride, n4);
+  for (int i = 4 * n4; i < n; i++) { float v = w[(long)i * stride]; p[0] = p[0] + v * v; }
+  for (int k = 1; k < 4; k++) p[0] = p[0] + p[k];
+  return p[0];
+}
+
+float oivae_oracle_col_sumsq(const float* W, int H, int K, int k) {
+  if (K == 1) {
+    float tmp[512];
+    for (int h = 0; h < H; h++) tmp[h] = W[h];
+    return oivae_oracle_row_sumsq(tmp, H);
+  }
+  int n_seq = (K >= 8) ? (K / 32) * 32 : (K / 4) * 4;
+  return (k < n_seq) ? multi_row_sumsq(W + k, K, H) : row_sum_sumsq(W + k, K, H);
+}
+
+/* W: the G maps stacked on rows, [sum H_g, K]; group_off: G+1 prefix sums of H_g.
+ * mask/norms [G, K].  Returns 0, or 1 if a shape is outside the pinned range. */
+int oivae_oracle_prox_cols_f32(float* W, const int32_t* group_off, int G, int K, float t,
+                               const uint16_t* tab, uint8_t* mask, float* norms_out) {
+  for (int g = 0; g < G; g++) {
+    int H = group_off[g + 1] - group_off[g];
+    if (H < 1 || H >= 512 || (long)H * K >= 32768) return 1;
+  }
+  for (int g = 0; g < G; g++) {
+    float* Wg = W + (long)group_off[g] * K;
+    int H = group_off[g + 1] - group_off[g];
+    for (int k = 0; k < K; k++) {
+      float n = oivae_oracle_mkl_sqrtf(oivae_oracle_col_sumsq(Wg, H, K, k), tab);
+      float den = n < 1e-16f ? 1e-16f : n;
+      if (n != n) den = n;
+      float sc = n - t;
+      if (sc < 0.0f) sc = 0.0f;
+      int allzero = 1;
+      for (int h = 0; h < H; h++) {
+        float v = Wg[(long)h * K + k] / den;
+        v = v * sc;
+        Wg[(long)h * K + k] = v;
+        if (!(v == 0.0f)) allzero = 0;
+      }
+      if (mask) mask[(long)g * K + k] = (uint8_t)allzero;
+      if (norms_out) norms_out[(long)g * K + k] = n;
+    }
+  }
+  return 0;
+}

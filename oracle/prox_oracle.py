@@ -38,6 +38,8 @@ def lib():
     L.oivae_oracle_prox_f32.restype = ctypes.c_int
     L.oivae_oracle_row_sumsq.argtypes = [vp, ctypes.c_int]
     L.oivae_oracle_row_sumsq.restype = ctypes.c_float
+    L.oivae_oracle_prox_cols_f32.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, vp, vp]
+    L.oivae_oracle_prox_cols_f32.restype = ctypes.c_int
     _tab = np.fromfile(_TABLE, dtype=np.uint16)
     assert _tab.size == 65536
     _lib = L
@@ -64,4 +66,22 @@ def proximal_step(Ws, t):
                                mask.ctypes.data, norms.ctypes.data)
   if rc != 0:
     raise ValueError("prox oracle: H=%d outside the pinned range" % H)
+  return W, mask, norms
+
+
+def proximal_step_cols(W, group_dims, t):
+  """FirstLayerSparseDecoder.proximal_step (/root/reference/lib/models.py:65-71) on the
+  maps stacked on rows, W [sum H_g, K].  Returns (new W, zero mask [G,K], column norms [G,K])."""
+  L = lib()
+  W = np.ascontiguousarray(W, np.float32).copy()
+  K = W.shape[1]
+  off = np.concatenate([[0], np.cumsum(group_dims)]).astype(np.int32)
+  assert off[-1] == W.shape[0]
+  G = len(group_dims)
+  mask = np.zeros((G, K), np.uint8)
+  norms = np.zeros((G, K), np.float32)
+  rc = L.oivae_oracle_prox_cols_f32(W.ctypes.data, off.ctypes.data, G, K, float(t), _tab.ctypes.data,
+                                    mask.ctypes.data, norms.ctypes.data)
+  if rc != 0:
+    raise ValueError("prox oracle: group shape outside the pinned range")
   return W, mask, norms

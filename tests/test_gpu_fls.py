@@ -1,0 +1,121 @@
+"""GPU parity of the autoencoder variant's proximal step:
+FirstLayerSparseDecoder.proximal_step, /root/reference/lib/models.py:65-71.
+(1) the HIP kernel, through the C ABI, against every golden case recorded from the
+reference -- bit-exact weights and zero set; (2) the host class driven as
+data_vs_test_loss_autoencoder.py:96-145 drives the reference's, against the same loop
+on the CPU with the oracle's proximal step: teacher-forced bit-exact prox every epoch,
+losses within fp32 tolerance."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _prox_cols_gpu(W, dims, t):
+  from oi_vae_amd import _lib
+  L = _lib.init_device(0)
+  K = W.shape[1]
+  Wd = torch.from_numpy(W).cuda().contiguous()
+  off = torch.tensor(np.concatenate([[0], np.cumsum(dims)]).astype(np.int32)).cuda()
+  mask = torch.zeros(len(dims), K, dtype=torch.uint8, device="cuda")
+  norms = torch.zeros(len(dims), K, dtype=torch.float32, device="cuda")
+  st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  _lib.check(L.oivae_prox_cols_f32(Wd.data_ptr(), off.data_ptr(), len(dims), K, int(max(dims)), float(t),
+                                   mask.data_ptr(), norms.data_ptr(), st), "oivae_prox_cols_f32")
+  torch.cuda.synchronize()
+  return Wd.cpu().numpy(), mask.cpu().numpy(), norms.cpu().numpy()
+
+
+def test_column_prox_kernel_bit_exact_on_reference_vectors():
+  d = np.load(os.path.join(GOLDEN, "fls_prox_vectors.npz"))
+  for name in d["names"]:
+    ci = name.split("_")[0]
+    W, dims, t = d[ci + "/W"], d[name + "/dims"], float(d[name + "/t"])
+    got, mask, norms = _prox_cols_gpu(W, dims, t)
+    want = d[name + "/out"]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
+    off = np.concatenate([[0], np.cumsum(dims)])
+    wmask = np.stack([(want[off[g]:off[g + 1]] == 0).all(0) for g in range(len(dims))]).astype(np.uint8)
+    assert np.array_equal(mask, wmask), name
+
+
+def test_column_prox_rejects_unpinned_shapes_and_empty_input():
+  from oi_vae_amd import _lib
+  L = _lib.init_device(0)
+  W = torch.zeros(600, 4, device="cuda")
+  off = torch.tensor([0, 600], dtype=torch.int32, device="cuda")
+  st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  assert L.oivae_prox_cols_f32(W.data_ptr(), off.data_ptr(), 1, 4, 600, 0.1, None, None, st) == 2  # OIVAE_E_SHAPE
+  assert b"pinned" in L.oivae_last_error()
+  assert L.oivae_prox_cols_f32(W.data_ptr(), off.data_ptr(), 0, 4, 1, 0.1, None, None, st) == 0     # no maps: no-op
+  assert L.oivae_prox_cols_f32(None, off.data_ptr(), 1, 4, 1, 0.1, None, None, st) == 1            # OIVAE_E_ARG
+
+
+def _make(image_size, dim_z, seed, cls):
+  torch.manual_seed(seed)
+  enc = torch.nn.Linear(image_size * image_size, dim_z, bias=False)
+  gens = [torch.nn.Sequential(torch.nn.Linear(1, image_size, bias=False), torch.nn.Tanh(),
+                              torch.nn.Linear(image_size, image_size, bias=False)) for _ in range(image_size)]
+  dec = cls(gens, [1 for _ in range(image_size)], dim_z)
+  return enc, dec
+
+
+def test_autoencoder_loop_matches_cpu_run_with_oracle_prox():
+  """data_vs_test_loss_autoencoder.py:96-145 with image_size 8: Adam on the reconstruction loss, then
+  decoder.proximal_step(lr * lam) every epoch."""
+  import oi_vae_amd as oi
+  from oracle import prox_oracle
+  image_size, dim_z, lr, lam, n = 8, 4, 1e-2, 0.1, 32
+  g = torch.Generator().manual_seed(3)
+  X = (torch.rand(n, image_size * image_size, generator=g) < 0.2).float()
+
+  class CpuDecoder(oi.FirstLayerSparseDecoder):  # same modules on the CPU, proximal step by the oracle
+    def proximal_step(self, t):
+      W = np.concatenate([m.weight.data.numpy() for m in self.latent_to_group_maps], 0)
+      self.pre = W.copy()
+      dims = [m.weight.shape[0] for m in self.latent_to_group_maps]
+      out, self.mask, _ = prox_oracle.proximal_step_cols(W, dims, t)
+      off = 0
+      for m, h in zip(self.latent_to_group_maps, dims):
+        m.weight.data.copy_(torch.from_numpy(out[off:off + h])); off += h
+      self.post = out
+
+  enc_c, dec_c = _make(image_size, dim_z, 7, CpuDecoder)
+  enc_g, dec_g = _make(image_size, dim_z, 7, oi.FirstLayerSparseDecoder)
+  enc_g.cuda(); dec_g.cuda()
+  Xg = X.cuda()
+  opt_c = torch.optim.Adam([{"params": enc_c.parameters(), "lr": lr}, {"params": dec_c.parameters(), "lr": lr}])
+  opt_g = torch.optim.Adam([{"params": enc_g.parameters(), "lr": lr}, {"params": dec_g.parameters(), "lr": lr}])
+
+  def loss_of(enc, dec, data):
+    r = dec(enc(data)) - data
+    return torch.sum(torch.pow(r, 2)) / data.size(0)
+
+  killed = 0
+  for epoch in range(40):
+    lc, lg = loss_of(enc_c, dec_c, X), loss_of(enc_g, dec_g, Xg)
+    assert abs(lc.item() - lg.item()) <= 2e-4 * max(1.0, abs(lc.item())), (epoch, lc.item(), lg.item())
+    pc, pg = dec_c.group_lasso_penalty().item(), dec_g.group_lasso_penalty().item()
+    assert abs(pc - pg) <= 2e-4 * max(1.0, abs(pc))
+    for opt, l in ((opt_c, lc), (opt_g, lg)):
+      opt.zero_grad(); l.backward(); opt.step()
+    t = lr * lam * (150.0 if epoch % 10 == 9 else 1.0)  # every tenth epoch a strong step so columns do die
+    dec_c.proximal_step(t)
+    dec_g.proximal_step(t)
+    # teacher-forced: the kernel on the CPU run's pre-prox bits gives the CPU run's post-prox bits
+    dims = [1] * image_size
+    got, mask, _ = _prox_cols_gpu(dec_c.pre, dims, t)
+    assert np.array_equal(got.view(np.uint32), dec_c.post.view(np.uint32)), epoch
+    assert np.array_equal(mask, dec_c.mask)
+    killed = int(dec_c.mask.sum())
+    # free-running: same zero set, weights within fp32 drift
+    assert np.array_equal(dec_g.zero_mask.cpu().numpy(), dec_c.mask), epoch
+    Wg = torch.cat([m.weight.data for m in dec_g.latent_to_group_maps], 0).cpu().numpy()
+    assert np.max(np.abs(Wg - dec_c.post)) <= 1e-4 * max(1.0, np.max(np.abs(dec_c.post)))
+  assert 0 < killed < image_size * dim_z
+  assert torch.allclose(dec_g.connectivity().cpu(), torch.from_numpy(np.sqrt((dec_c.post.reshape(image_size, 1, dim_z) ** 2).sum(1))), atol=1e-4)

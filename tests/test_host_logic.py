@@ -165,3 +165,14 @@ def test_shard_rows_rejects_uneven_split():
   assert parallel.shard_rows(64, 1, 2) == (32, 64)
   with pytest.raises(ValueError):
     parallel.shard_rows(65, 0, 2)
+
+
+def test_first_layer_sparse_decoder_has_no_cpu_fallback():
+  import oi_vae_amd as oi
+  dec = oi.FirstLayerSparseDecoder([torch.nn.Linear(1, 4, bias=False) for _ in range(3)], [1, 1, 1], 5)
+  z = torch.randn(2, 5)
+  assert dec(z).shape == (2, 12)                       # forward is plain torch, as in the reference
+  assert len(list(dec.parameters())) == 6
+  assert dec.group_lasso_penalty().item() > 0
+  with pytest.raises(oi.OivaeError):
+    dec.proximal_step(0.1)                             # the proximal step is the HIP kernel or nothing

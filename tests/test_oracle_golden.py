@@ -62,3 +62,22 @@ def test_oracle_tracks_reference(name):
     assert np.array_equal(mask, z[pre + "zero_mask"])
     # free-running zero set (holds for these fixtures; not guaranteed in general)
     assert np.array_equal(info["zero_mask"], z[pre + "zero_mask"]), (name, i)
+
+
+def test_column_prox_oracle_matches_reference_bits():
+  """FirstLayerSparseDecoder.proximal_step (lib/models.py:65-71): the oracle's column-sum order, MKL root and
+  two-rounding scale against 228 cases recorded from the reference (tests/golden/make_golden_fls.py)."""
+  from oracle import prox_oracle
+  d = np.load(os.path.join(GOLDEN, "fls_prox_vectors.npz"))
+  assert len(d["names"]) >= 200
+  for name in d["names"]:
+    ci = name.split("_")[0]
+    W, dims, t = d[ci + "/W"], d[name + "/dims"], float(d[name + "/t"])
+    got, mask, norms = prox_oracle.proximal_step_cols(W, dims, t)
+    want = d[name + "/out"]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
+    off = np.concatenate([[0], np.cumsum(dims)])
+    wmask = np.stack([(want[off[g]:off[g + 1]] == 0).all(0) for g in range(len(dims))]).astype(np.uint8)
+    assert np.array_equal(mask, wmask), name
+    # group_lasso_penalty (lib/models.py:59-63) is the sum of the column norms the step used
+    assert abs(float(norms.astype(np.float64).sum()) - float(d[name + "/pen"])) <= 2e-6 * max(1.0, abs(float(d[name + "/pen"])))
