@@ -1,0 +1,89 @@
+"""Data formats either side of the hot path: the bars
+sampler against images drawn by the reference under the same seeds, and the .amc
+reader/writer against its grammar (the reference's lark parser cannot run here:
+parity unpinned, see oi_vae_amd/mocap_data.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oi_vae_amd import bars_data, mocap_data
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+SAMPLE = """#!OML:ASF F:\\VICON\\USERDATA\\INSTALL\\rory3\\rory3.ASF
+:FULLY-SPECIFIED
+:DEGREES
+1
+root 9.37216 17.8693 -17.3198 -2.01677 -7.59696 -3.23164
+lowerback 2.30193 -0.395121 1.17299
+rhumerus -29.5133 -12.8185 -82.7731
+rradius 1.2e+1
+# a comment line
+2
+root 9.37285 17.8666 -17.3192 -2.06376 -7.58832 -3.1009
+lowerback 2.23572 -0.406032 1.14828
+rhumerus -29.5133 -12.8185 -82.7731
+rradius -.5
+"""
+
+
+def test_bars_sampler_draws_the_reference_images():
+  z = np.load(os.path.join(GOLDEN, "bars_samples.npz"))
+  torch.manual_seed(5)
+  one = torch.stack([bars_data.sample_one_bar_image(8).view(-1) for _ in range(16)]).numpy()
+  assert np.array_equal(one, z["one_bar_8"])
+  assert set(np.unique(one)) == {0.0, 0.5} and np.all((one.reshape(16, 8, 8) != 0).any(2).sum(1) == 1)
+  torch.manual_seed(6)
+  assert np.array_equal(bars_data.sample_many_bars_images(12, 16, 2.0, 0.0).numpy(), z["many_16"])
+  torch.manual_seed(7)
+  assert np.array_equal(bars_data.sample_bars_image(torch.full((5,), 0.4), torch.full((7,), 0.3)).numpy(), z["image_5x7"])
+
+
+def test_amc_parse_sample():
+  frames = mocap_data.parse_amc_data(SAMPLE)
+  assert [f[0] for f in frames] == [1, 2]
+  assert list(frames[0][1].keys()) == ["root", "lowerback", "rhumerus", "rradius"]
+  assert frames[0][1]["root"] == [9.37216, 17.8693, -17.3198, -2.01677, -7.59696, -3.23164]
+  assert frames[0][1]["rradius"] == [12.0] and frames[1][1]["rradius"] == [-0.5]
+  dims, arr = mocap_data.amc_to_array(frames, ["root", "rradius", "lowerback", "rhumerus"])
+  assert dims == {"root": 6, "rradius": 1, "lowerback": 3, "rhumerus": 3}
+  assert len(arr) == 2 and len(arr[0]) == 13 and arr[1][6] == -0.5
+
+
+@pytest.mark.parametrize("bad", [
+  "1\nroot 1 2 3\n",                                        # no preamble
+  ":FULLY-SPECIFIED\n:DEGREES\nroot 1 2\n",                  # measurement before a key frame
+  ":FULLY-SPECIFIED\n:DEGREES\n1\nroot 1 x 3\n",             # not a number
+  ":FULLY-SPECIFIED\n:DEGREES\n1\nroot\n",                   # joint without channels
+  ":FULLY-SPECIFIED\n:DEGREES\n1\n2\nroot 1\n",              # empty key frame
+])
+def test_amc_rejects_text_outside_the_grammar(bad):
+  with pytest.raises(ValueError):
+    mocap_data.parse_amc_data(bad)
+
+
+def test_amc_array_checks_frame_numbering_and_joint_sets():
+  frames = mocap_data.parse_amc_data(SAMPLE)
+  with pytest.raises(AssertionError):
+    mocap_data.amc_to_array(frames[1:], ["root", "lowerback", "rhumerus", "rradius"])   # ids must start at 1
+  with pytest.raises(AssertionError):
+    mocap_data.amc_to_array(frames, ["root", "lowerback", "rhumerus"])                  # joint sets must agree
+
+
+def test_amc_write_read_round_trip(tmp_path):
+  rng = np.random.default_rng(0)
+  joint_order = ["root", "lowerback", "lhand", "rtoes"]
+  joint_dims = {"root": 3, "lowerback": 3, "lhand": 2, "rtoes": 1}   # root: rotations only, as in the script
+  seq = rng.standard_normal((7, 9)).astype(np.float32) * 50
+  d = tmp_path / "cmu_mocap" / "subjects" / "07"
+  d.mkdir(parents=True)
+  path = mocap_data.subject_trial_path(7, 2, datadir=str(tmp_path))
+  assert path.endswith(os.path.join("cmu_mocap", "subjects", "07", "07_02.amc"))
+  mocap_data.save_amc(path, torch.from_numpy(seq), joint_order, joint_dims)
+  order, dims, arr = mocap_data.load_mocap_trial(7, 2, datadir=str(tmp_path))
+  assert order == joint_order and dims == {"root": 6, "lowerback": 3, "lhand": 2, "rtoes": 1}
+  arr = np.asarray(arr, np.float32)
+  assert arr.shape == (7, 12) and np.all(arr[:, :3] == 0)            # translations written as zeros
+  assert np.array_equal(arr[:, 3:], seq)                              # %.9g round-trips fp32 exactly
