@@ -88,9 +88,12 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
     w->n_bias = (int32_t)(bb > kBiasBlocks ? kBiasBlocks : bb);
   }
   w->bias_part = reinterpret_cast<double*>(take(sizeof(double) * kBiasBlocks * 2 * s.K));
-  w->n_theta = 1024;
-  w->theta_part = reinterpret_cast<double*>(take(sizeof(double) * 1024));
-  w->n_pen = 1024;
+  w->n_theta = 2048;  // 512 blocks per generator parameter array; every slot written each step
+  w->theta_part = reinterpret_cast<double*>(take(sizeof(double) * 2048));
+  {
+    int64_t pb = ((int64_t)s.G * s.K + 255) / 256;
+    w->n_pen = (int32_t)(pb > 1024 ? 1024 : pb);  // = penalty_kernel's grid: every slot written
+  }
   w->pen_part = reinterpret_cast<double*>(take(sizeof(double) * 1024));
   w->enc_splits = mfma_encoder_fwd_splits(s, B);
   w->dpre = reinterpret_cast<float*>(take(sizeof(float) * B * 2 * s.K * w->enc_splits));
@@ -124,18 +127,38 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 // ---- weight prior + penalty + scalar combination ---------------------------------
-// theta prior over a flat range: sum of theta^2 (double) and grad += theta/sigma^2
-__global__ __launch_bounds__(256) void theta_prior_kernel(const float* __restrict__ th,
-                                                          float* __restrict__ gr, int64_t n,
-                                                          float inv_var, double* __restrict__ part) {
+// theta prior over the four generator parameter arrays (blockIdx.y): sum of theta^2 (double) and
+// grad += theta/sigma^2.  Every block writes its partial slot (zero for an empty array): no memset.
+struct ThetaSegs {
+  const float* th[4];
+  float* gr[4];
+  int64_t n[4];
+};
+
+__global__ __launch_bounds__(256) void theta_prior_kernel(ThetaSegs sg, float inv_var, double* __restrict__ part) {
   __shared__ double sm[256];
+  const int q = blockIdx.y;
+  const float* __restrict__ th = sg.th[q];
+  float* __restrict__ gr = sg.gr[q];
+  const int64_t n = sg.n[q];
   double acc = 0.0;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  const bool vec = ((reinterpret_cast<uintptr_t>(th) | reinterpret_cast<uintptr_t>(gr)) & 15) == 0;
   for (; i < n; i += stride) {
-    const float x = th[i];
-    acc += (double)x * (double)x;
-    gr[i] = gr[i] + x * inv_var;
+    if (vec && i + 4 <= n) {
+      const float4 x = *reinterpret_cast<const float4*>(th + i);
+      float4 g = *reinterpret_cast<const float4*>(gr + i);
+      acc += (double)x.x * x.x + (double)x.y * x.y + (double)x.z * x.z + (double)x.w * x.w;
+      g.x += x.x * inv_var; g.y += x.y * inv_var; g.z += x.z * inv_var; g.w += x.w * inv_var;
+      *reinterpret_cast<float4*>(gr + i) = g;
+    } else {
+      for (int64_t j = i; j < n && j < i + 4; ++j) {
+        const float x = th[j];
+        acc += (double)x * (double)x;
+        gr[j] = gr[j] + x * inv_var;
+      }
+    }
   }
   sm[threadIdx.x] = acc;
   __syncthreads();
@@ -143,7 +166,7 @@ __global__ __launch_bounds__(256) void theta_prior_kernel(const float* __restric
     if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+  if (threadIdx.x == 0) part[(int64_t)q * gridDim.x + blockIdx.x] = sm[0];
 }
 
 __global__ __launch_bounds__(256) void penalty_kernel(const float* __restrict__ Ws, int64_t rows, int H,
@@ -279,25 +302,18 @@ extern "C" int oivae_finalize_f32(const oivae_shape_t* shape, const oivae_tensor
   const int64_t cnt[4] = {s.gen_type == OIVAE_GEN_MLP ? (int64_t)s.G * s.M * s.H : 0,
                           s.gen_type == OIVAE_GEN_MLP ? (int64_t)s.G * s.M : 0, (int64_t)s.D * hin,
                           (int64_t)s.D};
-  OIVAE_HIP_CHECK(hipMemsetAsync(w.theta_part, 0, sizeof(double) * w.n_theta, st));
   const float inv_var = 1.0f / (sigma_theta * sigma_theta);
   double n_theta_elems = 0;
-  const int slots = w.n_theta / 4;
+  ThetaSegs sg;
   for (int q = 0; q < 4; ++q) {
-    if (cnt[q] == 0) continue;
-    if (!th[q] || !gr[q]) return fail(OIVAE_E_ARG, "oivae_finalize_f32: null generator tensor %d", q);
+    if (cnt[q] != 0 && (!th[q] || !gr[q])) return fail(OIVAE_E_ARG, "oivae_finalize_f32: null generator tensor %d", q);
+    sg.th[q] = th[q]; sg.gr[q] = gr[q]; sg.n[q] = cnt[q];
     n_theta_elems += (double)cnt[q];
-    int64_t blocks = (cnt[q] + 255) / 256;
-    if (blocks > slots) blocks = slots;
-    hipLaunchKernelGGL(theta_prior_kernel, dim3((unsigned)blocks), dim3(256), 0, st, th[q], gr[q], cnt[q],
-                       inv_var, w.theta_part + q * slots);
-    OIVAE_LAUNCH_CHECK();
   }
+  hipLaunchKernelGGL(theta_prior_kernel, dim3((unsigned)(w.n_theta / 4), 4), dim3(256), 0, st, sg, inv_var, w.theta_part);
+  OIVAE_LAUNCH_CHECK();
   const int64_t rows = (int64_t)s.G * s.K;
-  int64_t pblocks = (rows + 255) / 256;
-  if (pblocks > w.n_pen) pblocks = w.n_pen;
-  OIVAE_HIP_CHECK(hipMemsetAsync(w.pen_part, 0, sizeof(double) * w.n_pen, st));
-  hipLaunchKernelGGL(penalty_kernel, dim3((unsigned)pblocks), dim3(256), 0, st, params->Ws, rows, s.H, w.pen_part);
+  hipLaunchKernelGGL(penalty_kernel, dim3((unsigned)w.n_pen), dim3(256), 0, st, params->Ws, rows, s.H, w.pen_part);
   OIVAE_LAUNCH_CHECK();
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, w.kl_part, w.n_kl, w.ll_part, w.n_ll,
                      w.theta_part, w.n_theta, w.pen_part, w.n_pen, n_theta_elems, sigma_theta, lam,

@@ -404,13 +404,22 @@ __global__ __launch_bounds__(256) void enc_bwd_pre(int64_t B, int K, int S, cons
   for (int j = tid; j < 2 * K; j += 256) bias_part[(int64_t)blockIdx.x * 2 * K + j] = col[j];
 }
 
+// one block per column j: the per-block partials are folded by a fixed-shape tree (deterministic)
 __global__ __launch_bounds__(256) void enc_bwd_bias_final(const double* __restrict__ bias_part, int nblk, int K,
                                                           float* __restrict__ dbmu, float* __restrict__ dbsig) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= 2 * K) return;
+  __shared__ double sm[256];
+  const int j = blockIdx.x;
   double acc = 0.0;
-  for (int b = 0; b < nblk; ++b) acc += bias_part[(int64_t)b * 2 * K + j];
-  if (j < K) dbmu[j] = (float)acc; else dbsig[j - K] = (float)acc;
+  for (int b = threadIdx.x; b < nblk; b += 256) acc += bias_part[(int64_t)b * 2 * K + j];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (j < K) dbmu[j] = (float)sm[0]; else dbsig[j - K] = (float)sm[0];
+  }
 }
 
 // dW[j][d] = sum_b dpre[b][j] X[b][d]; block = 32 j x 64 d, loops over all b in order
@@ -642,7 +651,7 @@ extern "C" int oivae_encoder_bwd_f32(const oivae_shape_t* shape, const oivae_ten
   hipLaunchKernelGGL(enc_bwd_pre, dim3((unsigned)w.n_bias), dim3(256), pre_lds, st, B, s.K, S, dz, dz_sn, dz_sk, eps, c,
                      prior_mu, prior_sigma, prior_rows == 1 ? 0 : s.K, mu_q, sig_q, ea, w.dpre, w.bias_part);
   OIVAE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(enc_bwd_bias_final, dim3((unsigned)((2 * s.K + 255) / 256)), dim3(256), 0, st, w.bias_part, w.n_bias,
+  hipLaunchKernelGGL(enc_bwd_bias_final, dim3((unsigned)(2 * s.K)), dim3(256), 0, st, w.bias_part, w.n_bias,
                      s.K, grads->enc_bmu, grads->enc_bsig);
   OIVAE_LAUNCH_CHECK();
   if (mfma_encoder_applies(s)) {
