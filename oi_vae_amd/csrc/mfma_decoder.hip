@@ -743,13 +743,18 @@ __global__ __launch_bounds__(256) void dec_mfma64_v4(MfmaDecArgs a) {
     c3[0] = w1a[0]; c3[1] = w1a[1]; c3[2] = w1a[2];
 
     // ---- P1  kC*(a1+b1)^T = (kC A) z^T + kC b1, tile by tile.  Under tile 0: dz atomics of the previous row tile, z image ----
+    // (one atomic every other slot over both tiles: at most ~16 stay in flight per wave, below the issue-stall range)
+    auto dz_atomic = [&](int t, int r) {
+      atomicAdd(reinterpret_cast<float*>(dzb + (int64_t)(32 * t + OIVAE_ROWC(r)) * rowbytes + voff_prev), zacc[t][r]);
+    };
     vphase1<32, false>(tacc[0], c3, w_p1(0), b_z, [&](int s) {
-      atomicAdd(reinterpret_cast<float*>(dzb + (int64_t)(32 * (s >> 4) + OIVAE_ROWC(s & 15)) * rowbytes + voff_prev),
-                zacc[s >> 4][s & 15]);
+      if (!(s & 1)) dz_atomic(0, s >> 1);
       if ((s & 3) == 3) *reinterpret_cast<f32x4*>(wrZ + 4 * (s >> 2)) = zreg[s >> 2];
     }, w_p1(1), c3);
-    vphase1<32, false>(tacc[1], c3, w_p1(1), b_z, [&](int s) { if (s >= 2 && s < 10) tanh_pair(tacc[0], s - 2); },
-                       [&](int i) { return w_p3a(i >> 1, i & 1); }, c4);
+    vphase1<32, false>(tacc[1], c3, w_p1(1), b_z, [&](int s) {
+      if (s & 1) dz_atomic(1, s >> 1);
+      if (s >= 2 && s < 10) tanh_pair(tacc[0], s - 2);
+    }, [&](int i) { return w_p3a(i >> 1, i & 1); }, c4);
     // ---- P3  mu^T = W2 t^T + b2.  k over t tile 0 first (tanh of tile 1 under it) ----
     vphase2w<16>(gacc[0], gacc[1], c4, w_p3a, [&](int s) { return tacc[0][s]; },
                  [&](int u) { if (u >= 2 && u < 10) tanh_pair(tacc[1], u - 2); }, w_p3b, c3);

@@ -23,6 +23,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 #define OIVAE_ROW(r, hh) (((r) & 3) + 8 * ((r) >> 2) + 4 * (hh))
+using ldsv_t = const volatile float __attribute__((address_space(3)))*;
 
 // ------------------------------------------------------------------------------
 // forward: pre[b][j] = sum_d X[b][d] * Wcat[j][d]
@@ -137,11 +138,15 @@ __global__ __launch_bounds__(256) void enc_fwd_gemm(const float* __restrict__ X,
 // backward: dW[j][d] = sum_b dpre[b][j] * X[b][d]
 //   workgroup tile = (32*TJ) rows j x 256 columns d; each wave owns all rows x 64 columns
 // ------------------------------------------------------------------------------
-template <int TJ>
-__global__ __launch_bounds__(256) void enc_bwd_gemm(const float* __restrict__ X, const float* __restrict__ dpre,
+template <int TJ, int ND>
+__global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void enc_bwd_gemm(const float* __restrict__ X, const float* __restrict__ dpre,
                                                     int64_t B, int D, int K, float* __restrict__ dWmu,
                                                     float* __restrict__ dWsig) {
-  constexpr int BJ = 32 * TJ, BD = 256;
+  // workgroup tile = (32*TJ) rows j x (128*ND) columns d; each wave owns all rows x 32*ND columns.
+  // ND == 1 halves the LDS footprint so that two workgroups share a CU: one computes while the other
+  // sits at its barrier or waits for its tile loads.
+  constexpr int BJ = 32 * TJ, BD = 128 * ND;
+  constexpr int X4 = 32 * BD / 4 / 256;  // float4 per thread for the X tile
   constexpr int P4 = 32 * BJ / 4 / 256;  // float4 per thread for the dpre tile (BJ=128: 4, 64: 2, 32: 1)
   static_assert(32 * BJ / 4 % 256 == 0, "tile/threads");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -151,12 +156,11 @@ __global__ __launch_bounds__(256) void enc_bwd_gemm(const float* __restrict__ X,
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int d0 = blockIdx.x * BD, j0 = blockIdx.y * BJ;
 
-  // X tile [32][256]: 8 float4 per thread; thread -> (row = f/64, c = f%64)
-  f32x4 rx[8], rp[P4];
+  f32x4 rx[X4], rp[P4];
   auto gload = [&](int64_t b0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int f = tid + 256 * i, row = f >> 6, c = f & 63;
+    for (int i = 0; i < X4; ++i) {
+      const int f = tid + 256 * i, row = f / (BD / 4), c = f % (BD / 4);
       const int64_t b = b0 + row;
       const int d = d0 + 4 * c;
       rx[i] = (b < B && d < D) ? *reinterpret_cast<const f32x4*>(X + b * (int64_t)D + d) : (f32x4)(0.f);
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256) void enc_bwd_gemm(const float* __restrict__ X,
     float* x = sX + buf * 32 * BD;
     float* p = sP + buf * 32 * BJ;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < X4; ++i) {
       const int f = tid + 256 * i;
       *reinterpret_cast<f32x4*>(x + 4 * f) = rx[i];
     }
@@ -184,9 +188,11 @@ __global__ __launch_bounds__(256) void enc_bwd_gemm(const float* __restrict__ X,
     }
   };
 
-  f32x16 acc[TJ][2];
+  f32x16 acc[TJ][ND];
 #pragma unroll
-  for (int i = 0; i < TJ; ++i) { acc[i][0] = (f32x16)(0.f); acc[i][1] = (f32x16)(0.f); }
+  for (int i = 0; i < TJ; ++i)
+#pragma unroll
+    for (int q = 0; q < ND; ++q) acc[i][q] = (f32x16)(0.f);
 
   const int64_t T = (B + 31) / 32;
   gload(0);
@@ -194,21 +200,32 @@ __global__ __launch_bounds__(256) void enc_bwd_gemm(const float* __restrict__ X,
   __syncthreads();
   for (int64_t t = 0; t < T; ++t) {
     if (t + 1 < T) gload((t + 1) * 32);
-    const float* p = sP + (t & 1) * 32 * BJ + l31;
-    const float* x = sX + (t & 1) * 32 * BD + wave * 64 + l31;
+    // Operands of k-step s+1 are read from LDS before the MFMAs of k-step s (two register sets), so the matrix
+    // pipe never waits for an LDS round trip inside a tile.  Volatile LDS pointers keep the reads in this order
+    // and out of ds_read2_b32 (whose 8-bit offsets would cost a VALU add per pair; a VALU instruction costs ~8
+    // cycles of fp32 matrix time, an LDS read ~1-2: DESIGN.md 3.1).
+    const ldsv_t p = (ldsv_t)(sP + (t & 1) * 32 * BJ + hh * BJ + l31);
+    const ldsv_t x = (ldsv_t)(sX + (t & 1) * 32 * BD + hh * BD + wave * (32 * ND) + l31);
+    float fa[2][TJ], fb[2][ND];
+#pragma unroll
+    for (int i = 0; i < TJ; ++i) fa[0][i] = p[32 * i];
+#pragma unroll
+    for (int q = 0; q < ND; ++q) fb[0][q] = x[32 * q];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const int row = 2 * s + hh;
-      float fa[TJ], fb[2];
+      if (s + 1 < 16) {
 #pragma unroll
-      for (int i = 0; i < TJ; ++i) fa[i] = p[row * BJ + 32 * i];
-      fb[0] = x[row * BD];
-      fb[1] = x[row * BD + 32];
+        for (int i = 0; i < TJ; ++i) fa[(s + 1) & 1][i] = p[2 * (s + 1) * BJ + 32 * i];
 #pragma unroll
-      for (int i = 0; i < TJ; ++i) {
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[0], acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[1], acc[i][1], 0, 0, 0);
+        for (int q = 0; q < ND; ++q) fb[(s + 1) & 1][q] = x[2 * (s + 1) * BD + 32 * q];
       }
+      __builtin_amdgcn_sched_barrier(0);  // the reads stay AHEAD of this step's MFMAs
+#pragma unroll
+      for (int i = 0; i < TJ; ++i)
+#pragma unroll
+        for (int q = 0; q < ND; ++q)
+          acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][i], fb[s & 1][q], acc[i][q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (t + 1 < T) lstore((t + 1) & 1);
     __syncthreads();
@@ -217,8 +234,8 @@ __global__ __launch_bounds__(256) void enc_bwd_gemm(const float* __restrict__ X,
 #pragma unroll
   for (int i = 0; i < TJ; ++i)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int d = d0 + wave * 64 + 32 * q + l31;
+    for (int q = 0; q < ND; ++q) {
+      const int d = d0 + wave * (32 * ND) + 32 * q + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = j0 + 32 * i + OIVAE_ROW(r, hh);
@@ -293,14 +310,15 @@ int launch_encoder_fwd_mfma(const oivae_shape_t& s, const oivae_tensors_t* param
   }
 }
 
-template <int TJ>
+template <int TJ, int ND>
 static int launch_bwd(const float* X, const float* dpre, int64_t B, int D, int K, float* dWmu, float* dWsig,
                       hipStream_t st) {
-  const size_t lds = sizeof(float) * 2 * 32 * (256 + 32 * TJ);
-  OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_gemm<TJ>),
+  constexpr int BD = 128 * ND;
+  const size_t lds = sizeof(float) * 2 * 32 * (BD + 32 * TJ);
+  OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_gemm<TJ, ND>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const dim3 grid((unsigned)((D + 255) / 256), (unsigned)((2 * K + 32 * TJ - 1) / (32 * TJ)));
-  hipLaunchKernelGGL((enc_bwd_gemm<TJ>), grid, dim3(256), lds, st, X, dpre, B, D, K, dWmu, dWsig);
+  const dim3 grid((unsigned)((D + BD - 1) / BD), (unsigned)((2 * K + 32 * TJ - 1) / (32 * TJ)));
+  hipLaunchKernelGGL((enc_bwd_gemm<TJ, ND>), grid, dim3(256), lds, st, X, dpre, B, D, K, dWmu, dWsig);
   OIVAE_LAUNCH_CHECK();
   return OIVAE_OK;
 }
@@ -310,9 +328,10 @@ int launch_encoder_bwd_mfma(const oivae_shape_t& s, const oivae_tensors_t* grads
   if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(dpre) & 15))
     return fail(OIVAE_E_ARG, "MFMA encoder: X and dpre must be 16-byte aligned");
   const int J = 2 * s.K;
-  if (J % 128 == 0) return launch_bwd<4>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st);
-  if (J % 64 == 0) return launch_bwd<2>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st);
-  return launch_bwd<1>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st);
+  // 128 x 128 tiles, two workgroups per CU: 8.84 ms against 8.98 ms for 128 x 256 at the scale-up shape
+  if (J % 128 == 0) return launch_bwd<4, 1>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st);
+  if (J % 64 == 0) return launch_bwd<2, 2>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st);
+  return launch_bwd<1, 2>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st);
 }
 
 }  // namespace oivae
