@@ -69,11 +69,16 @@ __global__ __launch_bounds__(256) void enc_fwd_gemm(const float* __restrict__ X,
     boff[i] = row * LD + 4 * c;
   }
   f32x4 ra[A4], rb[B4];
-  auto gload = [&](int k0) {
+  // split-K: blockIdx.z owns columns [kbeg, kend) of X and writes its own partial image of pre
+  const int kbeg = blockIdx.z * klen;
+  const int kend = (kbeg + klen < D) ? kbeg + klen : D;
+  const int c4 = 4 * (tid & 7);  // this thread's column inside a 32-wide K tile
+  auto gload = [&](int k0) {     // columns at or beyond kend read as zero (D need only be a multiple of 4)
+    const bool cok = (k0 + c4) < kend;
 #pragma unroll
-    for (int i = 0; i < A4; ++i) ra[i] = aok[i] ? *reinterpret_cast<const f32x4*>(aptr[i] + k0) : (f32x4)(0.f);
+    for (int i = 0; i < A4; ++i) ra[i] = (aok[i] && cok) ? *reinterpret_cast<const f32x4*>(aptr[i] + k0) : (f32x4)(0.f);
 #pragma unroll
-    for (int i = 0; i < B4; ++i) rb[i] = bok[i] ? *reinterpret_cast<const f32x4*>(bptr[i] + k0) : (f32x4)(0.f);
+    for (int i = 0; i < B4; ++i) rb[i] = (bok[i] && cok) ? *reinterpret_cast<const f32x4*>(bptr[i] + k0) : (f32x4)(0.f);
   };
   auto lstore = [&](int buf) {
     float* a = sA + buf * BM * LD;
@@ -90,10 +95,7 @@ __global__ __launch_bounds__(256) void enc_fwd_gemm(const float* __restrict__ X,
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[i][j] = (f32x16)(0.f);
 
-  // split-K: blockIdx.z owns columns [kbeg, kend) of X and writes its own partial image of pre
-  const int kbeg = blockIdx.z * klen;
-  const int kend = (kbeg + klen < D) ? kbeg + klen : D;
-  const int T = (kend - kbeg) / 32;
+  const int T = (kend - kbeg + 31) / 32;
   pre += (int64_t)blockIdx.z * B * J;
   gload(kbeg);
   lstore(0);
@@ -249,7 +251,8 @@ __global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void enc_bwd_gemm(const flo
 
 bool mfma_encoder_applies(const oivae_shape_t& s) {
   if (getenv("OIVAE_FORCE_GENERIC")) return false;  // test hook
-  return (s.D % 32 == 0) && ((2 * s.K) % 32 == 0);
+  // 16-byte alignment of the rows of X ([B, D]) and of dpre ([B, 2K]); partial tiles are masked
+  return (s.D % 4 == 0) && s.D >= 32 && (s.K % 2 == 0);
 }
 
 // tile shape (rows x cols of pre per workgroup) and K-splits for a given problem: big batches use
@@ -274,7 +277,7 @@ static FwdPlan plan_fwd(const oivae_shape_t& s, int64_t B) {
   else { p.cfg = 4; bm = 128; bn = 32; }
   const int64_t tiles = ((B + bm - 1) / bm) * ((J + bn - 1) / bn);
   int splits = 1;
-  const int ktiles = s.D / 32;
+  const int ktiles = (s.D + 31) / 32;
   while (splits < kMaxEncSplits && tiles * splits < 256 && ktiles / (splits * 2) >= 16) splits *= 2;
   p.splits = splits;
   return p;
@@ -292,7 +295,7 @@ static int launch_fwd(const float* X, int64_t B, int D, int K, const float* Wmu,
   const size_t lds = sizeof(float) * 2 * (BM + BN) * 36;
   OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_fwd_gemm<WM, WN, WGM, WGN>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int ktiles = D / 32;
+  const int ktiles = (D + 31) / 32;
   const int klen = ((ktiles + splits - 1) / splits) * 32;
   const dim3 grid((unsigned)((B + BM - 1) / BM), (unsigned)((2 * K + BN - 1) / BN), (unsigned)splits);
   hipLaunchKernelGGL((enc_fwd_gemm<WM, WN, WGM, WGN>), grid, dim3(256), lds, st, X, B, D, K, Wmu, Wsig, pre, klen);

@@ -135,3 +135,47 @@ def test_wide_prox_full_size_bit_exact_and_idempotent_zero_set():
   newly = (m2 == 1) & (wmask == 0)
   left = np.sqrt((want.astype(np.float64) ** 2).sum(-1))
   assert np.all(left[newly] <= 1.1e-6) and np.all(left[(m2 == 0)] > 0.9e-6)
+
+
+_ENC = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+from oi_vae_amd import Engine, ModelSpec
+dims = [37, 150, 91, 6, 64, 212]           # ragged groups, D = 560 (multiple of 4, not of 32)
+D, K = sum(dims), 10                       # 2K = 20: a partial column tile
+eng = Engine(ModelSpec(D=D, K=K, H=1, M=0, group_dims=dims, gen_type="linear"), device="cuda:0")
+g = torch.Generator(device="cuda").manual_seed(2)
+for n in ("enc_Wmu", "enc_bmu", "enc_Wsig", "enc_bsig", "gen_W2", "gen_b2"):
+  eng.p[n].copy_((torch.rand(eng.p[n].shape, generator=g, device="cuda") * 2 - 1) / 8)
+eng.p["log_sigma"].fill_(float(np.log(1e-2)))
+eng.p["Ws"].copy_(torch.randn(eng.p["Ws"].shape, generator=g, device="cuda"))
+B = 777                                     # ragged row tiles too
+X = torch.rand(B, D, generator=g, device="cuda")
+eps = torch.randn(2, B, K, generator=g, device="cuda")
+out = eng.forward_backward(X, eps, 0.7)
+torch.cuda.synchronize()
+np.savez(sys.argv[1], grads=eng.flat_grads.cpu().numpy(), sc=out["scalars"].cpu().numpy(), mu=out["mu_q"].cpu().numpy(),
+         off=np.array([eng.seg_off[n] for n in ("enc_Wmu", "enc_bmu", "enc_Wsig", "enc_bsig")]), n=np.array([eng.seg_numel["enc_Wmu"], K]))
+'''
+
+
+def test_mfma_encoder_on_ragged_shapes_agrees_with_generic(tmp_path):
+  """MEG-like shape (K=10, D=560, B=777): the MFMA encoder's masked partial tiles against the generic kernels."""
+  script = tmp_path / "enc.py"
+  script.write_text(_ENC % {"root": ROOT})
+  res = {}
+  for mode in ("mfma", "generic"):
+    env = dict(os.environ)
+    if mode == "generic":
+      env["OIVAE_FORCE_GENERIC"] = "1"
+    out = tmp_path / (mode + ".npz")
+    subprocess.run([sys.executable, str(script), str(out)], check=True, env=env, timeout=300)
+    res[mode] = np.load(out)
+  a, b = res["mfma"], res["generic"]
+  assert np.max(np.abs(a["mu"] - b["mu"])) <= 1e-5 * max(1.0, np.max(np.abs(b["mu"])))
+  assert np.max(np.abs(a["sc"][:6] - b["sc"][:6]) / np.maximum(np.abs(b["sc"][:6]), 1)) < 1e-5
+  nW, K = int(a["n"][0]), int(a["n"][1])
+  for o, n in zip(a["off"], (nW, K, nW, K)):
+    ga, gb = a["grads"][o:o + n], b["grads"][o:o + n]
+    assert np.max(np.abs(ga - gb)) <= 2e-5 * max(np.max(np.abs(gb)), 1e-30)
