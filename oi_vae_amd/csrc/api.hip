@@ -81,7 +81,7 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
     w->n_kl = (int32_t)(eb > kEncEpiBlocks ? kEncEpiBlocks : eb);
   }
   w->kl_part = reinterpret_cast<double*>(take(sizeof(double) * kEncEpiBlocks));
-  w->n_ll = s.G * plan.chunks;
+  w->n_ll = plan.flat ? flat_decoder_blocks(s) : s.G * plan.chunks;
   w->ll_part = reinterpret_cast<double*>(take(sizeof(double) * kMaxPartials));
   {
     int64_t bb = (B + 63) / 64;  // at least 64 rows per block
@@ -100,6 +100,7 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
   w->n_chunks = plan.chunks;
   w->p_dec = L.total;
   w->slab = reinterpret_cast<float*>(take(plan.chunks > 1 ? sizeof(float) * L.total * plan.chunks : 0));
+  w->flat = reinterpret_cast<float*>(take(plan.flat ? sizeof(float) * flat_decoder_floats(s, N, nullptr) : 0));
   w->total_bytes = off;
   if (p && bytes < off)
     return fail(OIVAE_E_WORKSPACE, "workspace too small: %lld < %lld bytes", (long long)bytes, (long long)off);

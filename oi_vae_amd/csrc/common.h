@@ -45,6 +45,7 @@ struct Workspace {
   double* bias_part;    int32_t n_bias;    // [n_bias, 2K] per-block column sums of dpre (encoder bias gradients)
   float*  slab;         int32_t n_chunks;  // [n_chunks, P_dec] decoder grad partials (n_chunks > 1)
   int64_t p_dec;                           // floats per decoder-grad slab
+  float*  flat;                            // flat (many-small-groups) decoder: Hc | Wc | Wk | Ct | dz partials
   int64_t total_bytes;
 };
 
@@ -81,9 +82,16 @@ struct DecPlan {
   int32_t chunks;   // row chunks (grid.y)
   int64_t lds_bytes;
   bool mfma;        // fast path applies
+  bool flat;        // many-small-groups path applies
 };
 
 DecPlan plan_decoder(const oivae_shape_t& s, int64_t N);
+
+// flat (many-small-groups) decoder, flat_decoder.hip
+struct FlatLayout { int64_t oHc, oWc, oWk, oCt, oDzp, total; int splits; };
+bool flat_decoder_applies(const oivae_shape_t& s, int64_t N);
+int64_t flat_decoder_floats(const oivae_shape_t& s, int64_t N, FlatLayout* L);
+int flat_decoder_blocks(const oivae_shape_t& s);
 int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, int64_t bytes,
                     Workspace* out);
 int check_shape(const oivae_shape_t* s);

@@ -494,6 +494,7 @@ int launch_encoder_bwd_mfma(const oivae_shape_t& s, const oivae_tensors_t* grads
 DecPlan plan_decoder(const oivae_shape_t& s, int64_t N) {
   DecPlan pl;
   pl.mfma = mfma_decoder_applies(s);
+  pl.flat = !pl.mfma && flat_decoder_applies(s, N);
   pl.DC = s.max_group_dim < 64 ? s.max_group_dim : 64;
   pl.R = 0;
   pl.lds_bytes = 0;
@@ -510,12 +511,16 @@ DecPlan plan_decoder(const oivae_shape_t& s, int64_t N) {
   if ((int64_t)s.G * c > kMaxPartials) c = kMaxPartials / s.G > 0 ? kMaxPartials / s.G : 1;
   pl.chunks = (int32_t)c;
   if (pl.mfma) pl.chunks = mfma_decoder_chunks(s, N);
+  if (pl.flat) pl.chunks = 1;
   return pl;
 }
 
 int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, const oivae_tensors_t* grads,
                         const float* X, int64_t B, int32_t S, const float* z, float gen_sig_off, float* dz,
                         Workspace& w, hipStream_t st);  // mfma_decoder.hip
+int launch_decoder_flat(const oivae_shape_t& s, const oivae_tensors_t* params, const oivae_tensors_t* grads,
+                        const float* X, int64_t B, int32_t S, const float* z, float gen_sig_off, float* dz,
+                        Workspace& w, hipStream_t st);  // flat_decoder.hip
 
 }  // namespace oivae
 
@@ -569,6 +574,7 @@ extern "C" int oivae_decoder_fwd_bwd_f32(const oivae_shape_t* shape, const oivae
   const DecPlan pl = plan_decoder(s, N);
   OIVAE_HIP_CHECK(hipMemsetAsync(dz, 0, sizeof(float) * N * s.K, st));
   if (pl.mfma) return launch_decoder_mfma(s, params, grads, X, B, S, z, gen_sig_off, dz, w, st);
+  if (pl.flat) return launch_decoder_flat(s, params, grads, X, B, S, z, gen_sig_off, dz, w, st);
   if (pl.R == 0)
     return fail(OIVAE_E_SHAPE, "oivae_decoder_fwd_bwd_f32: group weights do not fit LDS (K=%d H=%d M=%d)", s.K, s.H, s.M);
   const DecLayout L = dec_layout(s);

@@ -259,8 +259,7 @@ bool mfma_encoder_applies(const oivae_shape_t& s) {
 // 256-row tiles (X read once, weights re-read B/256 times from L2); small batches (data-parallel
 // shards) use 64-row tiles and split the reduction over D so that >= 256 workgroups exist.
 struct FwdPlan { int cfg; int splits; };
-static FwdPlan plan_fwd(const oivae_shape_t& s, int64_t B) {
-  const int J = 2 * s.K;
+static FwdPlan plan_fwd(int J, int D, int64_t B) {
   FwdPlan p;
   // 256-row tiles whenever split-K (at most kMaxEncSplits slices of D) can still put >= 256 workgroups on the chip:
   // they issue 128 MFMAs per wave per barrier and re-read the weights B/256 times instead of B/64
@@ -277,7 +276,7 @@ static FwdPlan plan_fwd(const oivae_shape_t& s, int64_t B) {
   else { p.cfg = 4; bm = 128; bn = 32; }
   const int64_t tiles = ((B + bm - 1) / bm) * ((J + bn - 1) / bn);
   int splits = 1;
-  const int ktiles = (s.D + 31) / 32;
+  const int ktiles = (D + 31) / 32;
   while (splits < kMaxEncSplits && tiles * splits < 256 && ktiles / (splits * 2) >= 16) splits *= 2;
   p.splits = splits;
   return p;
@@ -285,7 +284,7 @@ static FwdPlan plan_fwd(const oivae_shape_t& s, int64_t B) {
 
 int mfma_encoder_fwd_splits(const oivae_shape_t& s, int64_t B) {
   if (!mfma_encoder_applies(s)) return 1;
-  return plan_fwd(s, B).splits;
+  return plan_fwd(2 * s.K, s.D, B).splits;
 }
 
 template <int WM, int WN, int WGM, int WGN>
@@ -303,16 +302,37 @@ static int launch_fwd(const float* X, int64_t B, int D, int K, const float* Wmu,
   return OIVAE_OK;
 }
 
+// C[M, J] = A[M, Kd] * W[J, Kd]^T on the fp32 matrix cores (J even; rows of A and W 16-byte aligned).  With
+// `splits` > 1 (mfma_gemm_nt_splits) the reduction is cut into slices and C receives `splits` partial images
+// [splits][M][J] for the caller to add in index order.
+int mfma_gemm_nt_splits(int64_t M, int Kd, int J) { return plan_fwd(J, Kd, M).splits; }
+
+int mfma_gemm_nt(const float* A, int64_t M, int Kd, const float* W, int J, float* C, hipStream_t st) {
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (Kd % 4) || (J % 2))
+    return fail(OIVAE_E_ARG, "mfma_gemm_nt: operands must be 16-byte aligned, Kd a multiple of 4, J even");
+  const FwdPlan p = plan_fwd(J, Kd, M);
+  const int Kh = J / 2;
+  const float *Wm = W, *Wg = W + (int64_t)Kh * Kd;
+  switch (p.cfg) {
+    // 128 x 128 tiles at two workgroups per CU beat 256 x 128 at one (8.43 vs 8.7 ms at the scale-up shape,
+    // same box): one workgroup computes while the other sits at its barrier; the weights' extra L2 re-reads are free
+    case 5: return launch_fwd<2, 2, 2, 2>(A, M, Kd, Kh, Wm, Wg, C, p.splits, st);
+    case 0: return launch_fwd<2, 4, 4, 1>(A, M, Kd, Kh, Wm, Wg, C, p.splits, st);
+    case 1: return launch_fwd<1, 2, 2, 2>(A, M, Kd, Kh, Wm, Wg, C, p.splits, st);
+    case 2: return launch_fwd<2, 2, 4, 1>(A, M, Kd, Kh, Wm, Wg, C, p.splits, st);
+    case 3: return launch_fwd<1, 1, 2, 2>(A, M, Kd, Kh, Wm, Wg, C, p.splits, st);
+    default: return launch_fwd<1, 1, 4, 1>(A, M, Kd, Kh, Wm, Wg, C, p.splits, st);
+  }
+}
+
 int launch_encoder_fwd_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, const float* X, int64_t B,
                             float* pre, hipStream_t st) {
   if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(params->enc_Wmu) & 15) ||
       (reinterpret_cast<uintptr_t>(params->enc_Wsig) & 15))
     return fail(OIVAE_E_ARG, "MFMA encoder: X, Wmu, Wsig must be 16-byte aligned");
-  const FwdPlan p = plan_fwd(s, B);
+  const FwdPlan p = plan_fwd(2 * s.K, s.D, B);
   const float *Wm = params->enc_Wmu, *Wg = params->enc_Wsig;
   switch (p.cfg) {
-    // 128 x 128 tiles at two workgroups per CU beat 256 x 128 at one (8.43 vs 8.7 ms at the scale-up shape,
-    // same box): one workgroup computes while the other sits at its barrier; the weights' extra L2 re-reads are free
     case 5: return launch_fwd<2, 2, 2, 2>(X, B, s.D, s.K, Wm, Wg, pre, p.splits, st);
     case 0: return launch_fwd<2, 4, 4, 1>(X, B, s.D, s.K, Wm, Wg, pre, p.splits, st);
     case 1: return launch_fwd<1, 2, 2, 2>(X, B, s.D, s.K, Wm, Wg, pre, p.splits, st);
@@ -344,6 +364,18 @@ int launch_encoder_bwd_mfma(const oivae_shape_t& s, const oivae_tensors_t* grads
   if (J % 128 == 0) return launch_bwd<4, 1>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st);
   if (J % 64 == 0) return launch_bwd<2, 2>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st);
   return launch_bwd<1, 2>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st);
+}
+
+// C[J, Dn] = P[M, J]^T * X[M, Dn] on the fp32 matrix cores, rows of M added in order (deterministic).
+// J a multiple of 4, Dn a multiple of 4, operands 16-byte aligned.
+int mfma_gemm_tn(const float* P, const float* X, int64_t M, int J, int Dn, float* C, hipStream_t st) {
+  if ((reinterpret_cast<uintptr_t>(P) & 15) || (reinterpret_cast<uintptr_t>(X) & 15) || (J % 4) || (Dn % 4))
+    return fail(OIVAE_E_ARG, "mfma_gemm_tn: operands must be 16-byte aligned, J and Dn multiples of 4");
+  const int Kh = J / 2;
+  float* C2 = C + (int64_t)Kh * Dn;
+  if (J % 128 == 0) return launch_bwd<4, 1>(X, P, M, Dn, Kh, C, C2, st);
+  if (J % 64 == 0) return launch_bwd<2, 2>(X, P, M, Dn, Kh, C, C2, st);
+  return launch_bwd<1, 2>(X, P, M, Dn, Kh, C, C2, st);
 }
 
 }  // namespace oivae

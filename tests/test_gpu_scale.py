@@ -179,3 +179,55 @@ def test_mfma_encoder_on_ragged_shapes_agrees_with_generic(tmp_path):
   for o, n in zip(a["off"], (nW, K, nW, K)):
     ga, gb = a["grads"][o:o + n], b["grads"][o:o + n]
     assert np.max(np.abs(ga - gb)) <= 2e-5 * max(np.max(np.abs(gb)), 1e-30)
+
+
+_FLAT = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+from oi_vae_amd import Engine, ModelSpec
+typ, H, dg = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+G, K = 200, 48                                  # G not a multiple of the 16-group blocks, K a partial 32-tile
+eng = Engine(ModelSpec(D=G * dg, K=K, H=H, M=0, group_dims=[dg] * G, gen_type=typ), device="cuda:0")
+g = torch.Generator(device="cuda").manual_seed(4)
+for n in ("enc_Wmu", "enc_bmu", "enc_Wsig", "enc_bsig", "gen_W2", "gen_b2"):
+  scale = 0.25 if n.startswith("gen") else 0.01   # z of order one
+  eng.p[n].copy_((torch.rand(eng.p[n].shape, generator=g, device="cuda") * 2 - 1) * scale)
+eng.p["log_sigma"].copy_(torch.log(torch.rand(eng.p["log_sigma"].shape, generator=g, device="cuda") * 0.05 + 0.01))
+# small Ws keeps tanh out of saturation, where 1 - t^2 cancels and ANY fp32 evaluation order is only 1e-4 accurate
+eng.p["Ws"].copy_(0.15 * torch.randn(eng.p["Ws"].shape, generator=g, device="cuda"))
+B, S = 150, 3                                   # ragged row tiles, several Monte-Carlo samples
+X = torch.rand(B, G * dg, generator=g, device="cuda")
+eps = torch.randn(S, B, K, generator=g, device="cuda")
+out = eng.forward_backward(X, eps, 0.7)
+torch.cuda.synchronize()
+np.savez(sys.argv[1], grads=eng.flat_grads.cpu().numpy(), sc=out["scalars"].cpu().numpy())
+'''
+
+
+@pytest.mark.parametrize("typ,H,dg", [("linear", 8, 4), ("tanh_linear", 8, 8), ("tanh_linear", 4, 4), ("linear", 4, 8)])
+def test_flat_many_small_groups_decoder_agrees_with_generic(tmp_path, typ, H, dg):
+  """The GEMM-decomposed decoder for many small groups (wide-prox shape family) against the generic kernels."""
+  script = tmp_path / "flat.py"
+  script.write_text(_FLAT % {"root": ROOT})
+  res = {}
+  for mode in ("flat", "generic"):
+    env = dict(os.environ)
+    if mode == "generic":
+      env["OIVAE_FORCE_GENERIC"] = "1"
+    out = tmp_path / (mode + ".npz")
+    subprocess.run([sys.executable, str(script), str(out), typ, str(H), str(dg)], check=True, env=env, timeout=300)
+    res[mode] = np.load(out)
+  a, b = res["flat"], res["generic"]
+  assert np.max(np.abs(a["sc"][:6] - b["sc"][:6]) / np.maximum(np.abs(b["sc"][:6]), 1)) < 1e-5
+  from oi_vae_amd import ModelSpec
+  from oi_vae_amd.engine import _SEG_ORDER, _ALIGN
+  shapes = ModelSpec(D=200 * dg, K=48, H=H, M=0, group_dims=[dg] * 200, gen_type=typ).seg_shapes()
+  off = 0
+  for name in _SEG_ORDER:
+    n = int(np.prod(shapes[name]))
+    if n:
+      ga, gb = a["grads"][off:off + n], b["grads"][off:off + n]
+      err = np.max(np.abs(ga - gb)) / max(np.max(np.abs(gb)), 1e-30)
+      assert err < 2e-5, (name, err)
+    off += (n + _ALIGN - 1) // _ALIGN * _ALIGN
