@@ -1,5 +1,5 @@
-"""Diagonal Gaussian with the reference's interface
-(/root/reference/lib/distributions.py:27-57,88-95).
+"""Diagonal Gaussian, Gamma and distribution concatenation with the reference's
+interface (/root/reference/lib/distributions.py:27-95).
 
 These objects serve the calls the scripts make outside the training step
 (`generative_net(inference_net(X).mu).sample()` for plots,
@@ -41,8 +41,46 @@ class Normal(object):
     return Normal(self.mu.expand(size), self.sigma.expand(size))
 
 
+class Gamma(object):
+  """Gamma(shape, rate) observation model (lib/distributions.py:59-71).  The reference's
+  class has only `logprob`; `size` is added so that `_DistributionCat.logprob` can split
+  its argument (in the reference that call raises AttributeError for a Gamma member)."""
+
+  def __init__(self, shape, rate):
+    assert shape.size() == rate.size()
+    self.shape = shape
+    self.rate = rate
+
+  def size(self, *args, **kwargs):
+    return self.shape.size(*args, **kwargs)
+
+  def logprob(self, x):
+    return torch.sum(self.shape * torch.log(self.rate) - torch.lgamma(self.shape)
+                     + (self.shape - 1) * torch.log(x) - self.rate * x)
+
+
+class _DistributionCat(object):
+  """Concatenation of arbitrary member distributions along `dim`
+  (lib/distributions.py:73-86): evaluation-side only, the training step's fused
+  kernels take Normal outputs."""
+
+  def __init__(self, distributions, dim=-1):
+    self.distributions = distributions
+    self.dim = dim
+
+  def sample(self):
+    return torch.cat([d.sample() for d in self.distributions], dim=self.dim)
+
+  def logprob(self, x):
+    xs = torch.split(x, [d.size(self.dim) for d in self.distributions], dim=self.dim)
+    return sum(d.logprob(xx) for d, xx in zip(self.distributions, xs))
+
+  def entropy(self):
+    return sum(d.entropy() for d in self.distributions)
+
+
 def DistributionCat(distributions, dim=-1):
-  if not all(isinstance(d, Normal) for d in distributions):
-    raise NotImplementedError("only Normal group generators are on the oi-VAE path")
-  return Normal(mu=torch.cat([d.mu for d in distributions], dim=dim),
-                sigma=torch.cat([d.sigma for d in distributions], dim=dim))
+  if all(isinstance(d, Normal) for d in distributions):
+    return Normal(mu=torch.cat([d.mu for d in distributions], dim=dim),
+                  sigma=torch.cat([d.sigma for d in distributions], dim=dim))
+  return _DistributionCat(distributions, dim=-1)

@@ -115,6 +115,8 @@ class Engine:
     self.trace = None
     self.gen_sig_off = 1e-3
     self.bound = []  # (user tensor, grad view) pairs set by adopt()
+    self._eval_grads = None
+    self._eval_gt = None
 
   def _timed(self, name, fn):
     if self.trace is None:
@@ -220,7 +222,7 @@ class Engine:
 
   # ---- the step ----------------------------------------------------------------
   def forward_backward(self, X, eps, c, sig_off=1e-3, gen_sig_off=1e-3, prior_mu=None, prior_sigma=None,
-                       sigma_theta=1.0, lam=1.0, grad_sync=None):
+                       sigma_theta=1.0, lam=1.0, grad_sync=None, evaluate_only=False):
     """Forward + backward of loss = z_kl - loglik_term - logprob_theta
     (/root/reference/lib/oivae.py:43-75).  Fills ``flat_grads`` completely and
     returns mu_q, sig_q, z (fresh tensors) plus the 8-float scalar block.
@@ -229,7 +231,12 @@ class Engine:
     penalty + scalars (they need nothing from the encoder backward), encoder
     backward.  ``grad_sync`` (parallel.BucketedGradSync) is told when the decoder's
     and then the encoder's gradient segments are final, so that the data-parallel
-    all-reduce of the first overlaps the encoder backward."""
+    all-reduce of the first overlaps the encoder backward.
+
+    ``evaluate_only``: held-out evaluation (the log-likelihood the reference leaves
+    stubbed at meg_oi_vae.py:258-260).  The same kernels run, but every gradient goes
+    to a scratch image of ``flat_grads`` and the encoder backward is skipped, so
+    parameters, ``flat_grads`` and optimizer state are untouched."""
     s = self.spec
     with torch.cuda.device(self.device):
       X = self._dev_f32(X, "X")
@@ -258,6 +265,12 @@ class Engine:
       st = self._stream()
       L = self.lib
       sh, pt, gt = ctypes.byref(self._shape), ctypes.byref(self._pt), ctypes.byref(self._gt)
+      if evaluate_only:
+        if self._eval_gt is None:
+          self._eval_grads = torch.zeros_like(self.flat_grads)
+          shapes = s.seg_shapes()
+          self._eval_gt = self._tensors({n: self._view(self._eval_grads, n, shapes[n]) for n in _SEG_ORDER})
+        gt = ctypes.byref(self._eval_gt)
       _lib.check(self._timed("encoder_fwd", lambda: L.oivae_encoder_fwd_f32(
         sh, pt, X.data_ptr(), B, S, eps.data_ptr(), float(c), float(sig_off),
         prior_mu.data_ptr(), prior_sigma.data_ptr(), prior_rows,
@@ -269,6 +282,8 @@ class Engine:
       _lib.check(self._timed("finalize", lambda: L.oivae_finalize_f32(
         sh, pt, gt, B, S, float(sigma_theta), float(lam), self.scalars.data_ptr(),
         ws.data_ptr(), self._ws_bytes, st)), "oivae_finalize_f32")
+      if evaluate_only:
+        return dict(mu_q=mu_q, sig_q=sig_q, z=z, scalars=self.scalars, X=X, eps=eps)
       if grad_sync is not None:
         grad_sync.decoder_grads_ready()
       _lib.check(self._timed("encoder_bwd", lambda: L.oivae_encoder_bwd_f32(

@@ -87,6 +87,29 @@ class OIVAE(object):
       eng.sgd_prox_step(self._fused_sgd._lr(), prox_step_size, do_prox=True)
     elif self.lam > 0:
       self.generative_model.proximal_step(prox_step_size)
+    return self._info(out, scalars)
+
+  def evaluate(self, X, mc_samples, eps=None):
+    """Held-out evaluation: the terms of `step`'s return dict for a batch X with no
+    gradient, optimizer or proximal side effect (the test log-likelihood that the
+    reference leaves stubbed, meg_oi_vae.py:258-260).  Under data parallelism each
+    rank passes its shard and the scalars are combined as in `step`."""
+    eng = self.engine
+    if eps is None:
+      eps = torch.stack([torch.randn(X.size(0), eng.spec.K) for _ in range(mc_samples)])
+    c, sig_off = probe_encoder_head(self.inference_model)
+    pm, ps = self._prior()
+    out = eng.forward_backward(X.detach() if torch.is_tensor(X) else X, eps, c, sig_off=sig_off,
+                               gen_sig_off=eng.gen_sig_off, prior_mu=pm, prior_sigma=ps,
+                               sigma_theta=float(self.prior_theta.sigma), lam=float(self.lam),
+                               evaluate_only=True)
+    scalars = out["scalars"].clone()
+    if self.data_parallel and parallel.is_active(self.process_group):
+      parallel.reduce_scalars_(scalars, self.process_group)
+    return self._info(out, scalars)
+
+  @staticmethod
+  def _info(out, scalars):
     return {
       'q_z': Normal(out["mu_q"], out["sig_q"]),
       'z_kl': scalars[0],

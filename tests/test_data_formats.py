@@ -87,3 +87,28 @@ def test_amc_write_read_round_trip(tmp_path):
   arr = np.asarray(arr, np.float32)
   assert arr.shape == (7, 12) and np.all(arr[:, :3] == 0)            # translations written as zeros
   assert np.array_equal(arr[:, 3:], seq)                              # %.9g round-trips fp32 exactly
+
+
+def test_distribution_classes_match_reference_vectors():
+  """Gamma / Normal / _DistributionCat log-probabilities against values recorded from the
+  reference's classes (tests/golden/make_golden_dist.py) and, for Gamma, scipy's closed form."""
+  import os
+  import scipy.stats
+  import torch
+  from oi_vae_amd.distributions import DistributionCat, Gamma, Normal, _DistributionCat
+  v = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dist_vectors.npz"))
+  t = lambda k: torch.from_numpy(v[k])
+  got = Gamma(t("gamma_shape"), t("gamma_rate")).logprob(t("gamma_x")).item()
+  assert got == float(v["gamma_logprob"])
+  want = scipy.stats.gamma.logpdf(v["gamma_x"].astype(np.float64), v["gamma_shape"].astype(np.float64),
+                                  scale=1.0 / v["gamma_rate"].astype(np.float64)).sum()
+  assert abs(got - want) < 1e-4 * abs(want)
+  mu, sig, x = t("normal_mu"), t("normal_sigma"), t("normal_x")
+  assert Normal(mu, sig).logprob(x).item() == float(v["normal_logprob"])
+  parts = [Normal(mu[:, :4], sig[:, :4]), Normal(mu[:, 4:], sig[:, 4:])]
+  assert _DistributionCat(parts).logprob(x).item() == float(v["cat_logprob"])
+  assert isinstance(DistributionCat(parts), Normal) == bool(v["cat_is_normal"])
+  mixed = DistributionCat([parts[0], Gamma(t("gamma_shape"), t("gamma_rate"))])
+  assert isinstance(mixed, _DistributionCat)
+  xm = torch.cat([x[:, :4], t("gamma_x")], dim=1)
+  assert abs(mixed.logprob(xm).item() - (parts[0].logprob(x[:, :4]).item() + got)) < 1e-3

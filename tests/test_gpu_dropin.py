@@ -135,3 +135,33 @@ def test_inference_time_calls_work_on_adopted_model():
   assert gen.connectivity().shape == (29, 8)
   gen.proximal_step(100.0)
   assert float(gen.Ws.data.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["c2_mocap", "c4_tiny32"])
+def test_evaluate_gives_the_steps_terms_without_side_effects(name):
+  """Held-out evaluation (stubbed in the reference, meg_oi_vae.py:258-260): the terms of the
+  golden step, with parameters, gradients and optimizer state left alone."""
+  import oi_vae_amd as oi
+  z, spec = load(name)
+  holder = {"c": float(z["step0/c"])}
+  inference_net, gen = _build(spec, holder)
+  _load_into(inference_net, gen, params_at(z, spec, "init/"), spec["gen_type"])
+  opt = torch.optim.SGD([gen.Ws], lr=spec["Ws_lr"])
+  rows = z["step0/X"].shape[0] if spec["prior_rows"] == "B" else 1
+  vae = oi.OIVAE(inference_net, gen, oi.Normal(torch.zeros(rows, spec["K"]), torch.ones(rows, spec["K"])),
+                 oi.NormalPriorTheta(spec["sigma_theta"]), spec["lam"], [opt])
+  before = vae.engine.flat_params.clone()
+  grads_before = vae.engine.flat_grads.clone()
+  X, eps = torch.from_numpy(z["step0/X"]), torch.from_numpy(z["step0/eps"])
+  for _ in range(2):
+    info = vae.evaluate(X, eps.shape[0], eps=eps)
+    for k in SCALARS:
+      want = float(z["step0/" + k])
+      assert abs(info[k].item() - want) <= 1e-5 * max(abs(want), 1.0), (k, info[k].item(), want)
+    assert rel_err(info["q_z"].mu.cpu().numpy(), z["step0/mu_q"]) < 1e-5
+  assert torch.equal(vae.engine.flat_params, before)
+  assert torch.equal(vae.engine.flat_grads, grads_before)
+  assert gen.Ws.grad is None
+  # and a training step afterwards is still the golden one
+  info = vae.step(X, float(z["step0/t"]), eps.shape[0], eps=eps)
+  assert rel_err(gen.Ws.grad.cpu().numpy(), z["step0/grad/Ws"]) < 2e-5
