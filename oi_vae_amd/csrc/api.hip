@@ -95,12 +95,13 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
     w->n_pen = (int32_t)(pb > 1024 ? 1024 : pb);  // = penalty_kernel's grid: every slot written
   }
   w->pen_part = reinterpret_cast<double*>(take(sizeof(double) * 1024));
-  w->enc_splits = mfma_encoder_fwd_splits(s, B);
+  w->enc_splits = x3_encoder_applies(s) ? x3_encoder_fwd_splits(s, B) : mfma_encoder_fwd_splits(s, B);
   w->dpre = reinterpret_cast<float*>(take(sizeof(float) * B * 2 * s.K * w->enc_splits));
   w->n_chunks = plan.chunks;
   w->p_dec = L.total;
   w->slab = reinterpret_cast<float*>(take(plan.chunks > 1 ? sizeof(float) * L.total * plan.chunks : 0));
   w->flat = reinterpret_cast<float*>(take(plan.flat ? sizeof(float) * flat_decoder_floats(s, N, nullptr) : 0));
+  w->x3_img = reinterpret_cast<uint32_t*>(take(x3_encoder_ws_bytes(s, B)));
   w->total_bytes = off;
   if (p && bytes < off)
     return fail(OIVAE_E_WORKSPACE, "workspace too small: %lld < %lld bytes", (long long)bytes, (long long)off);

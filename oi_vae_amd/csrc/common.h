@@ -46,6 +46,7 @@ struct Workspace {
   float*  slab;         int32_t n_chunks;  // [n_chunks, P_dec] decoder grad partials (n_chunks > 1)
   int64_t p_dec;                           // floats per decoder-grad slab
   float*  flat;                            // flat (many-small-groups) decoder: Hc | Wc | Wk | Ct | dz partials
+  uint32_t* x3_img;                        // x3 encoder: split image of the weights (fwd) / of dpre (bwd)
   int64_t total_bytes;
 };
 
@@ -96,6 +97,15 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
                     Workspace* out);
 int check_shape(const oivae_shape_t* s);
 int mfma_encoder_fwd_splits(const oivae_shape_t& s, int64_t B);  // mfma_encoder.hip
+// x3_encoder.hip: fp32 GEMMs as six bf16 matrix products
+bool x3_encoder_applies(const oivae_shape_t& s);
+int64_t x3_encoder_ws_bytes(const oivae_shape_t& s, int64_t B);
+int x3_encoder_fwd_splits(const oivae_shape_t& s, int64_t B);
+bool x3_encoder_bwd_applies(const oivae_shape_t& s, int64_t B);
+int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X, const float* dpre,
+                          int64_t B, uint32_t* img, hipStream_t st);
+int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params, const float* X, int64_t B,
+                          float* pre, uint32_t* wimg, int splits, hipStream_t st);
 void launch_slab_reduce(const float* slab, int64_t P, int chunks, float* dst, int64_t seg_off, int64_t seg_n,
                         unsigned blocks, hipStream_t st);
 

@@ -541,7 +541,9 @@ extern "C" int oivae_encoder_fwd_f32(const oivae_shape_t* shape, const oivae_ten
   if (int rc = carve_workspace(*shape, B, S, workspace, workspace_bytes, &w)) return rc;
   hipStream_t st = (hipStream_t)stream;
   float* pre = w.dpre;  // [B, 2K]; the backward pass reuses the buffer for dpre
-  if (mfma_encoder_applies(*shape)) {
+  if (x3_encoder_applies(*shape)) {
+    if (int rc = launch_encoder_fwd_x3(*shape, params, X, B, pre, w.x3_img, w.enc_splits, st)) return rc;
+  } else if (mfma_encoder_applies(*shape)) {
     if (int rc = launch_encoder_fwd_mfma(*shape, params, X, B, pre, st)) return rc;
   } else {
     const int64_t blocks = (B + kEncRows - 1) / kEncRows;
@@ -660,7 +662,9 @@ extern "C" int oivae_encoder_bwd_f32(const oivae_shape_t* shape, const oivae_ten
   hipLaunchKernelGGL(enc_bwd_bias_final, dim3((unsigned)(2 * s.K)), dim3(256), 0, st, w.bias_part, w.n_bias,
                      s.K, grads->enc_bmu, grads->enc_bsig);
   OIVAE_LAUNCH_CHECK();
-  if (mfma_encoder_applies(s)) {
+  if (x3_encoder_bwd_applies(s, B)) {
+    if (int rc = launch_encoder_bwd_x3(s, grads, X, w.dpre, B, w.x3_img, st)) return rc;
+  } else if (mfma_encoder_applies(s)) {
     if (int rc = launch_encoder_bwd_mfma(s, grads, X, w.dpre, B, st)) return rc;
   } else {
     const dim3 grid((unsigned)((s.D + 63) / 64), (unsigned)((2 * s.K + 31) / 32));

@@ -1,0 +1,388 @@
+// Encoder GEMMs with fp32 operands carried as three bf16 terms each ("x3" kernels).
+//
+// Same products as mfma_encoder.hip -- forward pre[B, 2K] = X * [Wmu; Wsig]^T
+// (/root/reference/lib/models.py:15-16), backward [dWmu; dWsig] = dpre^T * X
+// (lib/oivae.py:75) -- but issued on the bf16 matrix instruction
+// v_mfma_f32_32x32x16_bf16, which retires 16x the flops per cycle of
+// v_mfma_f32_32x32x2_f32 on gfx950.  Every fp32 operand x is written EXACTLY as
+//     x = hi + mid + lo,   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)
+// (round to nearest even; the two subtractions are exact in fp32, 3 x 8 significand
+// bits cover fp32's 24), and a product a*b is accumulated in fp32 from the six
+// partial products of weight >= 2^-16:
+//     a_hi b_hi + a_hi b_mid + a_mid b_hi + a_hi b_lo + a_lo b_hi + a_mid b_mid .
+// The three dropped ones (mid*lo, lo*mid, lo*lo) are below 2^-24 |a b|, i.e. below
+// the rounding of the fp32 product itself; each partial product of two bf16 numbers
+// is exact in fp32 and the matrix unit accumulates in fp32, so the result carries the
+// same error as the fp32 MFMA chain (measured: tests/test_gpu_scale.py).
+// Non-finite inputs give NaN where the fp32 kernels give +-inf (inf - inf in the split).
+//
+// The streamed operand (X, 17 GB) is split in registers on its way into LDS; the small
+// operand (the weights / the pre-activation gradients) is split once per step into an
+// image laid out the way LDS wants it.  Roofline: 6/16 of the fp32 MFMA time, which at
+// the scale-up shape puts both GEMMs at the HBM time of reading X once.
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace oivae {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+#define OIVAE_ROW(r, hh) (((r) & 3) + 8 * ((r) >> 2) + 4 * (hh))
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {  // low half = bf16(a), high half = bf16(b), RNE
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// (a, b) -> packed bf16 pairs of the three terms
+struct Split3 { uint32_t h, m, l; };
+__device__ __forceinline__ Split3 split_pair(float a, float b) {
+  Split3 r;
+  r.h = cvt_pk_bf16(a, b);
+  const float ra = a - __uint_as_float(r.h << 16), rb = b - __uint_as_float(r.h & 0xffff0000u);
+  r.m = cvt_pk_bf16(ra, rb);
+  const float sa = ra - __uint_as_float(r.m << 16), sb = rb - __uint_as_float(r.m & 0xffff0000u);
+  r.l = cvt_pk_bf16(sa, sb);
+  return r;
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// six partial products of one 32x32x16 step; fa/fb = {hi, mid, lo}
+template <int NI, int NJ>
+__device__ __forceinline__ void x3_step(f32x16 (&acc)[NI][NJ], const u32x4 (&fa)[NI][3], const u32x4 (&fb)[NJ][3]) {
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // small terms first
+#pragma unroll
+  for (int q = 0; q < 6; ++q)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = mfma_bf16(fa[i][PA[q]], fb[j][PB[q]], acc[i][j]);
+}
+
+// ------------------------------------------------------------------------------
+// Split image of a row-major operand W[rows][Kd] (reduction index contiguous):
+//   img[row][kt][s][piece][16]  (bf16), kt = k / 32, s = (k / 16) & 1, inside: k & 15
+// rows beyond `rows` and columns beyond Kd are zero.  One thread per 8 consecutive k.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void x3_split_rows(const float* __restrict__ W0, const float* __restrict__ W1,
+                                                     int rows0, int rows, int Kd, int rows_pad, int KT,
+                                                     uint32_t* __restrict__ img) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)rows_pad * KT * 4;  // 8-wide chunks
+  if (i >= total) return;
+  const int row = (int)(i / (KT * 4)), c = (int)(i % (KT * 4));
+  const int kt = c >> 2, s = (c >> 1) & 1, h = c & 1;
+  const int k = 8 * c;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  if (row < rows) {
+    const float* src = (row < rows0 ? W0 + (int64_t)row * Kd : W1 + (int64_t)(row - rows0) * Kd);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (k + e < Kd) v[e] = src[k + e];
+  }
+  u32x4 P[3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const Split3 q = split_pair(v[2 * e], v[2 * e + 1]);
+    P[0][e] = q.h; P[1][e] = q.m; P[2][e] = q.l;
+  }
+  uint32_t* dst = img + (((int64_t)row * KT + kt) * 2 + s) * 24 + 4 * h;  // 24 dwords per (row, kt, s)
+#pragma unroll
+  for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + 8 * p) = P[p];
+}
+
+// ------------------------------------------------------------------------------
+// forward: pre[b][j] = sum_d X[b][d] * W[j][d];  workgroup tile 128 rows x 128 columns, reduction in macro tiles
+// of 32 (two MFMA steps of 16).  Twelve waves with three roles (one of each per SIMD):
+//   waves 0-3   consumers: 64 x 64 of the tile each; LDS operand reads and the 48 MFMAs of a macro tile, nothing else;
+//   waves 4-7   X producers: global loads of X four macro tiles ahead (HBM latency under load is ~3 us), the
+//               fp32 -> 3 x bf16 split, LDS writes;
+//   waves 8-11  W producers: the weight image from L2, four tiles ahead, copied to LDS.  (Loads return in order per
+//               wave: in one queue the L2 hits would wait behind the HBM loads.)
+// The producers' VALU/LDS/VMEM instructions issue in the shadow of the consumers' MFMAs (tools/probe/mfma_probe3).
+// LDS holds two macro tiles (112 KB); ONE barrier per macro tile: before it the consumers have read tile t into
+// registers and the producers have written tile t+1, after it the consumers' remaining MFMAs of tile t run from
+// registers while tile t+1 is read, so no LDS latency is exposed either.
+// LDS row r of sub-step s = 28 dwords: piece p at +8p, lane-half h at +4h (8 bf16 = one MFMA operand).
+// ------------------------------------------------------------------------------
+constexpr int kX3Row = 28;                      // dwords per LDS row: 24 + 4 pad (28*l mod 64: 16 distinct multiples of 4)
+constexpr int kX3Buf = 4 * 128 * kX3Row;        // dwords per macro tile: X [2][128][28] | W [2][128][28]
+constexpr int kX3StagesX = 4;                   // X macro tiles in flight per producer
+constexpr int kX3StagesW = 4;
+
+// BWD = false: out0 = pre [B, J] (+ split-K images), M side = rows of X (k = d contiguous), N side = weight image.
+// BWD = true : out0/out1 = dWmu/dWsig [K, D]; the reduction runs over the batch: M side = 128 columns d of X
+//              (transposed on the way into LDS: bf16 pairs are formed from two consecutive rows; LDS row
+//              rho = 32 (d & 3) + (d >> 2) keeps those writes conflict-free), N side = the image of dpre^T.
+//              B is a multiple of 32 and D of 128 on this path.
+template <bool BWD>
+__global__ __launch_bounds__(768, 1) void enc_x3_gemm(const float* __restrict__ X, int64_t B, int D, int J,
+                                                      const uint32_t* __restrict__ Wimg, int KT,
+                                                      float* __restrict__ out0, float* __restrict__ out1, int klen) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint32_t* lds = reinterpret_cast<uint32_t*>(smem_raw);  // [2][kX3Buf]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * 128;  // first row of X (forward) / first column d (backward)
+  const int j0 = blockIdx.y * 128;
+  const int kbeg = BWD ? 0 : blockIdx.z * klen;
+  const int kend = BWD ? (int)B : ((kbeg + klen < D) ? kbeg + klen : D);
+  const int T = (kend - kbeg) / 32;  // D (forward) / B (backward) is a multiple of 32 on this path
+  // every role passes the same number of barriers: T rounded up to a multiple of 4 (the producers' loops are
+  // unrolled over their register rings and contain no branch: a branch around a memory instruction makes the
+  // compiler drain the prefetch queue; tiles past the end are copies of the last one, written to a buffer
+  // that nobody reads any more)
+  const int Tr = (T + 3) & ~3;
+  float* pre = out0;
+  if (!BWD) pre += (int64_t)blockIdx.z * B * J;
+
+  if (wave >= 8) {
+    // ---------------- W producers ----------------
+    const int tid = threadIdx.x - 512;
+    const uint32_t* wptr[6];
+    int woff[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int f = tid + 256 * i, row = f / 12, ch = f % 12;
+      const int s = ch / 6, p = (ch % 6) >> 1, h = ch & 1;
+      wptr[i] = Wimg + ((int64_t)(j0 + row) * KT + (kbeg >> 5)) * 48 + 4 * ch;
+      woff[i] = 2 * 128 * kX3Row + (s * 128 + row) * kX3Row + 8 * p + 4 * h;
+    }
+    u32x4 rw[kX3StagesW][6];
+    auto wload = [&](int t, u32x4 (&r)[6]) {
+      const int64_t kt = (t < T ? t : T - 1);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) r[i] = *reinterpret_cast<const u32x4*>(wptr[i] + kt * 48);
+    };
+    auto wstore = [&](int buf, const u32x4 (&w)[6]) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4*>(lds + buf * kX3Buf + woff[i]) = w[i];
+    };
+    // tile u lives in rw[u % 4]
+    wload(0, rw[0]); wload(1, rw[1]); wload(2, rw[2]); wload(3, rw[3]);
+    wstore(0, rw[0]);
+    wload(4, rw[0]);
+    __syncthreads();  // P_{-1}: tile 0 is in LDS
+    auto step = [&](int t, u32x4 (&w)[6]) {  // writes tile t+1, refills with tile t+5
+      wstore((t + 1) & 1, w);
+      wload(t + 5, w);
+      __syncthreads();  // P_t
+    };
+    for (int t = 0; t < Tr; t += 4) {
+      step(t, rw[1]); step(t + 1, rw[2]); step(t + 2, rw[3]); step(t + 3, rw[0]);
+    }
+  } else if (wave >= 4) {
+    // ---------------- X producers ----------------
+    const int tid = threadIdx.x - 256;
+    const float* xptr[4];
+    int xoff;
+    if (!BWD) {
+      const int xr = tid >> 3, xc = tid & 7;
+      // rows beyond B re-read row B-1 (their results are never stored): no load is conditional
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t row = m0 + xr + 32 * i;
+        xptr[i] = X + (row < B ? row : B - 1) * (int64_t)D + kbeg + 4 * xc;
+      }
+      xoff = ((xc >> 2) * 128 + xr) * kX3Row + 4 * ((xc >> 1) & 1) + 2 * (xc & 1);
+    } else {
+      const int c = tid & 31, rg = tid >> 5;  // columns d = m0 + 4c..4c+3, rows 4 rg..4 rg+3 of the macro tile
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xptr[i] = X + (int64_t)(4 * rg + i) * D + m0 + 4 * c;
+      xoff = ((rg >> 2) * 128 + c) * kX3Row + 4 * ((rg >> 1) & 1) + 2 * (rg & 1);
+    }
+    const int64_t xstep = BWD ? 32 * (int64_t)D : 32;
+    f32x4 rx[kX3StagesX][4];
+    auto xload = [&](int t, f32x4 (&r)[4]) {  // tiles past the end re-read the last one (never used)
+      const int64_t k0 = xstep * (t < T ? t : T - 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const f32x4*>(xptr[i] + k0);
+    };
+    auto xstore = [&](int buf, const f32x4 (&r)[4]) {
+      uint32_t* base = lds + buf * kX3Buf;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u32x2 P[3];
+        // forward: r[i] = 4 consecutive k of row i; backward: column i of 4 consecutive rows (k) -> LDS row 32 i + c
+        const Split3 q0 = BWD ? split_pair(r[0][i], r[1][i]) : split_pair(r[i][0], r[i][1]);
+        const Split3 q1 = BWD ? split_pair(r[2][i], r[3][i]) : split_pair(r[i][2], r[i][3]);
+        P[0] = u32x2{q0.h, q1.h}; P[1] = u32x2{q0.m, q1.m}; P[2] = u32x2{q0.l, q1.l};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(base + xoff + 32 * i * kX3Row + 8 * p) = P[p];
+      }
+    };
+    // tile u lives in rx[u % 4]
+    xload(0, rx[0]); xload(1, rx[1]); xload(2, rx[2]); xload(3, rx[3]);
+    xstore(0, rx[0]);
+    xload(4, rx[0]);
+    __syncthreads();  // P_{-1}
+    auto step = [&](int t, f32x4 (&r)[4]) {  // writes tile t+1, refills with tile t+5
+      xstore((t + 1) & 1, r);
+      xload(t + 5, r);
+      __syncthreads();  // P_t
+    };
+    for (int t = 0; t < Tr; t += 4) {
+      step(t, rx[1]); step(t + 1, rx[2]); step(t + 2, rx[3]); step(t + 3, rx[0]);
+    }
+  } else {
+    // ---------------- consumers ----------------
+    const int wm = wave >> 1, wn = wave & 1;
+    const uint32_t* a0 = lds + (wm * 64 + l31) * kX3Row + 4 * hh;
+    const uint32_t* b0 = lds + 2 * 128 * kX3Row + (wn * 64 + l31) * kX3Row + 4 * hh;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
+    u32x4 fa[2][2][3], fb[2][2][3];  // [sub-step][tile][piece]
+    auto lread = [&](int buf, int s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          fa[s][i][p] = *reinterpret_cast<const u32x4*>(a0 + buf * kX3Buf + (s * 128 + 32 * i) * kX3Row + 8 * p);
+          fb[s][i][p] = *reinterpret_cast<const u32x4*>(b0 + buf * kX3Buf + (s * 128 + 32 * i) * kX3Row + 8 * p);
+        }
+    };
+    __syncthreads();  // P_{-1}
+    for (int t = 0; t < T; ++t) {
+      lread(t & 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t > 0) x3_step<2, 2>(acc, fa[1], fb[1]);  // second half of tile t-1, from registers
+      __builtin_amdgcn_sched_barrier(0);
+      lread(t & 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      x3_step<2, 2>(acc, fa[0], fb[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();  // P_t: tile t is in registers, tile t+1 is in LDS
+    }
+    x3_step<2, 2>(acc, fa[1], fb[1]);
+    for (int t = T; t < Tr; ++t) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = j0 + (wn * 2 + j) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int mrow = (wm * 2 + i) * 32 + OIVAE_ROW(r, hh);
+          if (!BWD) {
+            const int64_t row = m0 + mrow;
+            if (row < B && col < J) pre[row * J + col] = acc[i][j][r];
+          } else {
+            const int64_t d = m0 + 4 * (mrow & 31) + (mrow >> 5);  // LDS row rho -> column of X
+            const int Kh = J / 2;
+            if (col < J) (col < Kh ? out0 + (int64_t)col * D : out1 + (int64_t)(col - Kh) * D)[d] = acc[i][j][r];
+          }
+        }
+      }
+  }
+}
+
+// Split image of dpre^T: img[j][bt][s][piece][16 b] from dpre [B, J]; rows j >= J and b >= B are zero.
+// One thread per (j, 8 consecutive b); consecutive threads take consecutive j (coalesced reads).
+__global__ __launch_bounds__(256) void x3_split_cols(const float* __restrict__ P, int64_t B, int J, int rows_pad, int BT,
+                                                     uint32_t* __restrict__ img) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)rows_pad * BT * 4;
+  if (i >= total) return;
+  const int j = (int)(i % rows_pad);
+  const int64_t c = i / rows_pad;  // 8-chunk of b
+  const int64_t bt = c >> 2;
+  const int s = (int)(c >> 1) & 1, h = (int)c & 1;
+  const int64_t b = 8 * c;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (j < J && b + e < B) ? P[(b + e) * J + j] : 0.f;
+  u32x4 Q[3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const Split3 q = split_pair(v[2 * e], v[2 * e + 1]);
+    Q[0][e] = q.h; Q[1][e] = q.m; Q[2][e] = q.l;
+  }
+  uint32_t* dst = img + (((int64_t)j * BT + bt) * 2 + s) * 24 + 4 * h;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + 8 * p) = Q[p];
+}
+
+// ---- host side ------------------------------------------------------------------
+bool mfma_encoder_applies(const oivae_shape_t& s);  // mfma_encoder.hip
+
+bool x3_encoder_applies(const oivae_shape_t& s) {
+  if (!mfma_encoder_applies(s)) return false;
+  const char* e = getenv("OIVAE_ENC");  // test hook: OIVAE_ENC=fp32 keeps the fp32 matrix instructions
+  if (e && e[0] == 'f') return false;
+  return (2 * s.K) % 128 == 0 && s.D % 32 == 0;
+}
+
+static inline int x3_rows_pad(int J) { return (J + 127) / 128 * 128; }
+static inline int x3_ktiles(int Kd) { return (Kd + 31) / 32; }
+
+bool x3_encoder_bwd_applies(const oivae_shape_t& s, int64_t B) {
+  return x3_encoder_applies(s) && s.D % 128 == 0 && B % 32 == 0;
+}
+
+int64_t x3_encoder_ws_bytes(const oivae_shape_t& s, int64_t B) {
+  if (!x3_encoder_applies(s)) return 0;
+  const int64_t kt = x3_ktiles(s.D), bt = x3_encoder_bwd_applies(s, B) ? (B + 31) / 32 : 0;
+  return (int64_t)x3_rows_pad(2 * s.K) * (kt > bt ? kt : bt) * 48 * 4;  // 3 x bf16 per element of the larger image
+}
+
+int x3_encoder_fwd_splits(const oivae_shape_t& s, int64_t B) {
+  const int64_t tiles = ((B + 127) / 128) * (x3_rows_pad(2 * s.K) / 128);
+  int splits = 1;
+  const int ktiles = x3_ktiles(s.D);
+  while (splits < kMaxEncSplits && tiles * splits < 512 && ktiles / (splits * 2) >= 16) splits *= 2;
+  return splits;
+}
+
+int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params, const float* X, int64_t B,
+                          float* pre, uint32_t* wimg, int splits, hipStream_t st) {
+  if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(wimg) & 15))
+    return fail(OIVAE_E_ARG, "x3 encoder: X and the workspace must be 16-byte aligned");
+  const int J = 2 * s.K, Jp = x3_rows_pad(J), KT = x3_ktiles(s.D);
+  const int64_t chunks = (int64_t)Jp * KT * 4;
+  hipLaunchKernelGGL(x3_split_rows, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, params->enc_Wmu,
+                     params->enc_Wsig, s.K, J, s.D, Jp, KT, wimg);
+  OIVAE_LAUNCH_CHECK();
+  const size_t lds = sizeof(uint32_t) * 2 * kX3Buf;
+  OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_x3_gemm<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int klen = ((KT + splits - 1) / splits) * 32;
+  const dim3 grid((unsigned)((B + 127) / 128), (unsigned)(Jp / 128), (unsigned)splits);
+  hipLaunchKernelGGL(enc_x3_gemm<false>, grid, dim3(768), lds, st, X, B, s.D, J, wimg, KT, pre, (float*)nullptr, klen);
+  OIVAE_LAUNCH_CHECK();
+  return OIVAE_OK;
+}
+
+int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X, const float* dpre,
+                          int64_t B, uint32_t* img, hipStream_t st) {
+  if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(img) & 15))
+    return fail(OIVAE_E_ARG, "x3 encoder: X and the workspace must be 16-byte aligned");
+  const int J = 2 * s.K, Jp = x3_rows_pad(J);
+  const int BT = (int)((B + 31) / 32);
+  const int64_t chunks = (int64_t)Jp * BT * 4;
+  hipLaunchKernelGGL(x3_split_cols, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, dpre, B, J, Jp, BT, img);
+  OIVAE_LAUNCH_CHECK();
+  const size_t lds = sizeof(uint32_t) * 2 * kX3Buf;
+  OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_x3_gemm<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const dim3 grid((unsigned)(s.D / 128), (unsigned)(Jp / 128), 1);
+  hipLaunchKernelGGL(enc_x3_gemm<true>, grid, dim3(768), lds, st, X, B, s.D, J, img, BT, grads->enc_Wmu,
+                     grads->enc_Wsig, 0);
+  OIVAE_LAUNCH_CHECK();
+  return OIVAE_OK;
+}
+
+}  // namespace oivae

@@ -72,16 +72,25 @@ __global__ __launch_bounds__(TPB) void probe(float* out, const float* in, int it
 static float *g_out, *g_in;
 static long long* g_cyc;
 
+static double g_mhz = 0;  // shader clock of the last run: s_memtime cycles / hipEvent time
+
 template <int F, int N, int NACC, int TPB>
-double run() {
-  const int iters = 2000, blocks = 256;
+double run(int iters = 2000) {
+  const int blocks = 256;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   hipLaunchKernelGGL((probe<F, N, NACC, TPB>), dim3(blocks), dim3(TPB), 0, 0, g_out, g_in, 10, g_cyc);
+  (void)hipEventRecord(e0, 0);
   hipLaunchKernelGGL((probe<F, N, NACC, TPB>), dim3(blocks), dim3(TPB), 0, 0, g_out, g_in, iters, g_cyc);
+  (void)hipEventRecord(e1, 0);
   (void)hipDeviceSynchronize();
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
   long long h[256];
   (void)hipMemcpy(h, g_cyc, sizeof(h), hipMemcpyDeviceToHost);
   double sum = 0;
   for (int i = 0; i < 256; ++i) sum += (double)h[i];
+  g_mhz = sum / 256 / (ms * 1e3);
   return sum / 256 / ((double)iters * 16);
 }
 
@@ -99,6 +108,12 @@ int main() {
   (void)hipMemcpy(g_in, h, 16384 * 4, hipMemcpyHostToDevice);
   printf("bf16 32x32x16 chain, cycles per MFMA: one accumulator %.1f, two accumulators %.1f; two waves per SIMD (per pair) %.1f\n",
          run<F_NONE, 1, 1, 256>(), run<F_NONE, 1, 2, 256>(), run<F_NONE, 1, 2, 512>());
+  for (int rep = 0; rep < 3; ++rep) {
+    const double c1 = run<F_NONE, 1, 2, 256>(200000);
+    const double f1 = g_mhz;
+    const double c2 = run<F_NONE, 1, 2, 512>(100000);
+    printf("sustained bf16 chain (~0.1-0.2 s): 1 wave/SIMD %.1f cycles/MFMA at %.0f MHz; 2 waves/SIMD %.1f per pair at %.0f MHz\n", c1, f1, c2, g_mhz);
+  }
   row<F_VMOV>("v_mov_b32");
   row<F_PKADD>("v_pk_add_f32");
   row<F_CVT>("v_cvt_pk_bf16_f32");
