@@ -224,6 +224,10 @@ def main():
                            "executed_frac is the matrix-pipe utilisation"},
       "step_model_tflops": (decoder_flops_per_row() + encoder_flops_per_row()) * GLOBAL_BATCH / (ms * 1e-3) / 1e12 / world,
       "entry_ms": {k: sum(v) / len(v) for k, v in per_kernel.items()},
+      "arithmetic": "fp32 in, fp32 out, fp32 accumulation everywhere.  Decoder: v_mfma_f32_32x32x2_f32.  Encoder GEMMs: "
+                    "each fp32 operand carried exactly as three bf16 terms, six bf16 matrix products per fp32 product "
+                    "(x3_encoder.hip); error against float64 no larger than the fp32 matrix instructions' "
+                    "(tests/test_gpu_x3.py); OIVAE_ENC=fp32 selects the fp32 instructions",
     }
     if world == 1:
       out["prox_roofline"] = prox_roofline(device)
