@@ -31,6 +31,7 @@
 // Roofline: MFMA-bound.  9 products x 2*32*64*64 flops per 32-row tile = 576
 // v_mfma_f32_32x32x2_f32 per wave-tile.
 #include "common.h"
+#include "x3_split.h"
 
 #include <stdlib.h>
 #include <type_traits>
@@ -548,6 +549,92 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a_, f32x2 b_) {
   return r;
 }
 
+// ---- end of an all-64 decoder kernel: the four waves' partials of dW2 and P are summed in a fixed order through
+// LDS, dW1 = P Ws and dWs = P^T W1 are formed (two 64^3 fp32 products per group), and the per-column sums become
+// db2, dlog_sigma, db1 and the group's log-likelihood partial.  `stage`: >= 4*4096 + 64*65 floats; sP, uW1: 64*65 each.
+__device__ __forceinline__ void dec64_finish(const MfmaDecArgs& a, int g, int chunk, int tid, int wave, int lane,
+                                             f32x16 (&dW2a)[2][2], f32x16 (&Pa)[2][2], float cs_gmu, float cs_gmu2,
+                                             float cs_da1, float* stage, float* sP, float* uW1) {
+  constexpr int K = 64, H = 64, M = 64, DG = 64, LW = 65;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const float* Wsg = a.Ws + (int64_t)g * K * H;
+  const float* W1g = a.W1 + (int64_t)g * M * H;
+
+  // ---- reduce the four waves' partials in a fixed order (as v3) ----
+  const int64_t cs = a.chunk_stride * chunk;
+  auto stage_acc = [&](f32x16 (&acc)[2][2]) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stage[wave * 4096 + (32 * i + OIVAE_ROW(r, hh)) * 64 + 32 * j + l31] = acc[i][j][r];
+    __syncthreads();
+  };
+  stage_acc(dW2a);
+  {
+    float* dst = a.gW2 + cs + (int64_t)g * DG * M;
+    for (int idx = tid; idx < 4096; idx += 256)
+      dst[idx] = ((stage[idx] + stage[4096 + idx]) + stage[2 * 4096 + idx]) + stage[3 * 4096 + idx];
+  }
+  stage_acc(Pa);
+  float* uWs = stage + 4 * 4096;
+  for (int idx = tid; idx < 4096; idx += 256) {
+    const int o = (idx >> 6) * LW + (idx & 63);
+    sP[o] = ((stage[idx] + stage[4096 + idx]) + stage[2 * 4096 + idx]) + stage[3 * 4096 + idx];
+    uW1[o] = W1g[idx];
+    uWs[o] = Wsg[idx];
+  }
+  __syncthreads();
+  {
+    const int it = wave >> 1, ht = wave & 1;
+    f32x16 acc = (f32x16)(0.f);  // dW1[m][h] = sum_k P[m][k] Ws[k][h]
+    const float* pa = sP + (32 * it + l31) * LW + hh;
+    const float* pb = uWs + hh * LW + 32 * ht + l31;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) acc = mf32(pa[2 * s], pb[2 * s * LW], acc);
+    float* d1 = a.gW1 + cs + (int64_t)g * M * H;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d1[(32 * it + OIVAE_ROW(r, hh)) * H + 32 * ht + l31] = acc[r];
+    acc = (f32x16)(0.f);         // dWs[k][h] = sum_m P[m][k] W1[m][h]
+    pa = sP + hh * LW + 32 * it + l31;
+    pb = uW1 + hh * LW + 32 * ht + l31;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) acc = mf32(pa[2 * s * LW], pb[2 * s * LW], acc);
+    float* d2 = a.gWs + cs + (int64_t)g * K * H;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d2[(32 * it + OIVAE_ROW(r, hh)) * H + 32 * ht + l31] = acc[r];
+  }
+  stage[wave * 192 + lane] = cs_gmu;
+  stage[wave * 192 + 64 + lane] = cs_gmu2;
+  stage[wave * 192 + 128 + lane] = cs_da1;
+  __syncthreads();
+  float* sred = stage + 1024;
+  if (tid < 64) {
+    const float s_gmu = ((stage[tid] + stage[192 + tid]) + stage[384 + tid]) + stage[576 + tid];
+    const float s_gmu2 = ((stage[64 + tid] + stage[256 + tid]) + stage[448 + tid]) + stage[640 + tid];
+    const float s_da1 = ((stage[128 + tid] + stage[320 + tid]) + stage[512 + tid]) + stage[704 + tid];
+    const int64_t d = (int64_t)g * DG + tid;
+    const float e = expf(a.ls[d]);
+    const float sg = e + a.sig_off;
+    const float c2 = a.inv / sg;
+    const float sumq2 = s_gmu2 / (c2 * c2);
+    const float nrows = (chunk == 0) ? (float)a.N : 0.f;
+    a.gb2[cs + d] = s_gmu;
+    a.gls[cs + d] = (nrows - sumq2) * (e * a.inv / sg);
+    a.gb1[cs + (int64_t)g * M + tid] = s_da1;
+    sred[tid] = nrows * (-0.5f * kLog2Pi - logf(sg)) - 0.5f * sumq2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < 64; ++i) tot += (double)sred[i];
+    a.ll_part[(int64_t)chunk * gridDim.x + g] = tot;
+  }
+}
+
 __global__ __launch_bounds__(256) void dec_mfma64_v4(MfmaDecArgs a) {
   constexpr int K = 64, H = 64, M = 64, DG = 64;
   constexpr int LW = 65, LDB = 68;
@@ -810,84 +897,304 @@ __global__ __launch_bounds__(256) void dec_mfma64_v4(MfmaDecArgs a) {
         atomicAdd(reinterpret_cast<float*>(dzb + (int64_t)(32 * t + OIVAE_ROWC(r)) * rowbytes + voff_prev), zacc[t][r]);
   }
   const float cs_gmu = s1p[0] + s1p[1], cs_gmu2 = s2p[0] + s2p[1], cs_da1 = s3p[0] + s3p[1];
+  // A's two copies and W2 are dead: P and W1 take their places
+  dec64_finish(a, g, chunk, tid, wave, lane, dW2a, Pa, cs_gmu, cs_gmu2, cs_da1, sAct, sAf, sW2);
+}
 
-  // ---- reduce the four waves' partials in a fixed order (as v3) ----
-  const int64_t cs = a.chunk_stride * chunk;
-  float* stage = sAct;
-  auto stage_acc = [&](f32x16 (&acc)[2][2]) {
+// ------------------------------------------------------------------------------------------------------------
+// dec_x3_64: the all-64 decoder on the bf16 matrix instruction, every fp32 operand carried as three bf16 terms
+// (x3_split.h; six partial products per fp32 product, fp32 accumulation: fp32-grade results at 6/16 of the fp32
+// MFMA time).  Same mathematics as dec_mfma64_v4 (composed first layer A = W1 Ws^T), different data flow:
+//   * weights sit in LDS as MFMA-ready split images (one 1 KB fragment per (row block, 16 reduction slots, term)):
+//     kC A (rows m), A^T (rows k), W2 (rows d), W2^T (rows m);
+//   * every activation is computed in BOTH orientations, transposed (lane = batch row, registers = features:
+//     the accumulator is the next layer's operand after a split in registers) and plain (lane = feature,
+//     registers = batch rows: the accumulator is, after the same split, the operand of the weight-gradient
+//     products, whose reduction runs over batch rows).  The same operand registers serve both -- only the
+//     A/B roles of the MFMA swap -- so the duplicates cost matrix instructions (7 + 2 products instead of
+//     4 + 2) but no LDS round trip, no transposition and no workgroup barrier in the row loop;
+//   * column sums (db1, db2, sum of squares for log-lik and dlog_sigma) are plain per-lane adds in the
+//     feature-on-lane orientation.
+// The reduction slot order of a chained operand follows the accumulator layout: slot e of lane half hh in step
+// ks is feature 16 ks + 8 (e / 4) + 4 hh + e % 4; the weight images are built in that order.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kX3DecLds = (4 * 6144 + 192 + 3 * 64 * 65) * 4;  // images | b1, b2, c3 | fp32 staging
+
+__device__ __forceinline__ int x3_slot_feature(int ks, int hh, int e) { return 16 * ks + 8 * (e >> 2) + 4 * hh + (e & 3); }
+
+__global__ __launch_bounds__(256) void dec_x3_64(MfmaDecArgs a) {
+  constexpr int K = 64, H = 64, M = 64, DG = 64, LW = 65;
+  constexpr float kC = 2.885390081777927f;  // 2*log2(e): tanh(x) = 1 - 2/(exp2(kC x) + 1)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint32_t* img = reinterpret_cast<uint32_t*>(smem_raw);   // [4][2 rb][4 ks][3 terms][64 lanes][4 dwords]
+  float* sb1 = reinterpret_cast<float*>(img + 4 * 6144);   // kC * b1
+  float* sb2 = sb1 + 64;
+  float* sC3 = sb2 + 64;                                   // inv / sigma_d^2
+  float* scr = sC3 + 64;                                   // 3 x [64][65] fp32 staging
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int g = blockIdx.x, chunk = blockIdx.y, nchunks = gridDim.y;
+  {
+    float* tW1 = scr;
+    float* tWs = scr + 64 * LW;
+    float* tW2 = scr + 2 * 64 * LW;
+    const float* Wsg = a.Ws + (int64_t)g * K * H;
+    const float* W1g = a.W1 + (int64_t)g * M * H;
+    const float* W2g = a.W2 + (int64_t)g * DG * M;
+    for (int i = tid; i < 4096; i += 256) {
+      const int o = (i >> 6) * LW + (i & 63);
+      tW1[o] = W1g[i];
+      tWs[o] = Wsg[i];
+      tW2[o] = W2g[i];
+    }
+    if (tid < 64) {
+      const float sg = expf(a.ls[(int64_t)g * DG + tid]) + a.sig_off;
+      sb1[tid] = kC * a.b1[(int64_t)g * M + tid];
+      sb2[tid] = a.b2[(int64_t)g * DG + tid];
+      sC3[tid] = (a.inv / sg) / sg;
+    }
     __syncthreads();
+    // A[m][k] = sum_h W1[m][h] Ws[k][h] (fp32 fma chain), 16 entries per thread, then in place of W1
+    float av[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = tid + 256 * i, m = idx >> 6, k = idx & 63;
+      float acc = 0.f;
+      for (int h = 0; h < 64; ++h) acc = fmaf(tW1[m * LW + h], tWs[k * LW + h], acc);
+      av[i] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = tid + 256 * i;
+      tW1[(idx >> 6) * LW + (idx & 63)] = av[i];
+    }
+    __syncthreads();
+    const float* A = tW1;
+    // the four split images: item = (row r, step ks, lane half h2) -> 8 slots -> three 16-byte terms
+    for (int item = tid; item < 512; item += 256) {
+      const int r = item >> 3, ks = (item >> 1) & 3, h2 = item & 1;
+      float v[4][8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = x3_slot_feature(ks, h2, e);
+        v[0][e] = kC * A[r * LW + c];   // kC A   : rows m, reduction over k
+        v[1][e] = A[c * LW + r];        // A^T    : rows k, reduction over m
+        v[2][e] = tW2[r * LW + c];      // W2     : rows d, reduction over m
+        v[3][e] = tW2[c * LW + r];      // W2^T   : rows m, reduction over d
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const Frag3 f = split8(v[q][0], v[q][1], v[q][2], v[q][3], v[q][4], v[q][5], v[q][6], v[q][7]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          *reinterpret_cast<x3_u32x4*>(img + q * 6144 + ((((r >> 5) * 4 + ks) * 3 + p) * 64 + h2 * 32 + (r & 31)) * 4) = f.p[p];
+      }
+    }
+    __syncthreads();
+  }
+  const uint32_t* imgl = img + lane * 4;
+  auto wfrag = [&](int which, int rb, int ks) {
+    Frag3 f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) f.p[p] = *reinterpret_cast<const x3_u32x4*>(imgl + which * 6144 + ((rb * 4 + ks) * 3 + p) * 256);
+    return f;
+  };
+  // operand of 16 reduction slots from accumulator registers 8q..8q+7
+  auto afrag = [&](const f32x16& v, int q) {
+    return split8(v[8 * q], v[8 * q + 1], v[8 * q + 2], v[8 * q + 3], v[8 * q + 4], v[8 * q + 5], v[8 * q + 6], v[8 * q + 7]);
+  };
+  // accumulator := vector in transposed layout (register r <-> feature 32 rb + OIVAE_ROW(r, hh))
+  auto init_t = [&](f32x16& acc, const float* vec, int rb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(vec + 32 * rb + 8 * q + 4 * hh);
+      acc[4 * q] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
+    }
+  };
+
+  f32x16 dW2a[2][2], Pa[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { dW2a[i][j] = (f32x16)(0.f); Pa[i][j] = (f32x16)(0.f); }
+  float sg1[2] = {0.f, 0.f}, sg2[2] = {0.f, 0.f}, sd1[2] = {0.f, 0.f};  // per-lane column sums (feature 32 b + l31)
+
+  const int N32 = (int)a.N;
+  const int ntiles = (N32 + 31) / 32;
+  const bool one_sample = (a.N == a.B);
+  for (int tile = chunk * 4 + wave; tile < ntiles; tile += 4 * nchunks) {
+    const int r0 = tile * 32;
+    const bool full = (r0 + 32 <= N32);
+    const int nT = (r0 + l31 < N32) ? r0 + l31 : N32 - 1;   // this lane's batch row in the transposed orientation
+    const float liveT = (r0 + l31 < N32) ? 1.0f : 0.0f;
+    auto row_n = [&](int r) { const int n = r0 + OIVAE_ROW(r, hh); return n < N32 ? n : N32 - 1; };  // plain orientation
+    auto xrow = [&](int n) { return one_sample ? (int64_t)n : (int64_t)n % a.B; };
+
+    // ---- z in both orientations ----
+    Frag3 zf[4], zNf[2][2];
+    {
+      const float* zp = a.z + (int64_t)nT * K + 4 * hh;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(zp + 16 * ks), v1 = *reinterpret_cast<const f32x4*>(zp + 16 * ks + 8);
+        zf[ks] = split8(v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16 zn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zn[r] = a.z[(int64_t)row_n(r) * K + 32 * kb + l31];
+        zNf[kb][0] = afrag(zn, 0);
+        zNf[kb][1] = afrag(zn, 1);
+      }
+    }
+    // ---- kC (a1 + b1), both orientations; t = tanh ----
+    f32x16 tT[2], tN[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      init_t(tT[rb], sb1, rb);
+      const float bn = sb1[32 * rb + l31];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tN[rb][r] = bn;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const Frag3 w = wfrag(0, rb, ks);
+        x3mm(tT[rb], w, zf[ks]);
+        x3mm(tN[rb], zf[ks], w);
+      }
+    }
+    Frag3 tf[4], tNf[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        tT[rb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(tT[rb][r]) + 1.0f);
+        tN[rb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(tN[rb][r]) + 1.0f);
+      }
+      tf[2 * rb] = afrag(tT[rb], 0); tf[2 * rb + 1] = afrag(tT[rb], 1);
+      tNf[rb][0] = afrag(tN[rb], 0); tNf[rb][1] = afrag(tN[rb], 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {  // from here on only 1 - t^2 is needed
+        tT[rb][r] = 1.0f - tT[rb][r] * tT[rb][r];
+        tN[rb][r] = 1.0f - tN[rb][r] * tN[rb][r];
+      }
+    }
+    // ---- mu, both orientations; gmu = (mu - x) inv / sigma^2 ----
+    f32x16 gT[2], gN[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      init_t(gT[rb], sb2, rb);
+      const float bn = sb2[32 * rb + l31];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gN[rb][r] = bn;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const Frag3 w = wfrag(2, rb, ks);
+        x3mm(gT[rb], w, tf[ks]);
+        x3mm(gN[rb], tf[ks], w);
+      }
+    }
+    Frag3 gf[4], gNf[2][2];
+    {
+      const float* xT = a.X + xrow(nT) * (int64_t)a.D + (int64_t)g * DG + 4 * hh;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        f32x16 c3;
+        init_t(c3, sC3, rb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(xT + 32 * rb + 8 * q);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) gT[rb][4 * q + i] = (gT[rb][4 * q + i] - x[i]) * (c3[4 * q + i] * liveT);
+        }
+        const float cn = sC3[32 * rb + l31];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = r0 + OIVAE_ROW(r, hh);
+          const float x = a.X[xrow(n < N32 ? n : N32 - 1) * (int64_t)a.D + (int64_t)g * DG + 32 * rb + l31];
+          float v = (gN[rb][r] - x) * cn;
+          if (!full) v = (n < N32) ? v : 0.f;
+          gN[rb][r] = v;
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        }
+        sg1[rb] += s1;
+        sg2[rb] += s2;
+        gf[2 * rb] = afrag(gT[rb], 0); gf[2 * rb + 1] = afrag(gT[rb], 1);
+        gNf[rb][0] = afrag(gN[rb], 0); gNf[rb][1] = afrag(gN[rb], 1);
+      }
+    }
+    // ---- dW2[d][m] += sum_n gmu[n][d] t[n][m] ----
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          stage[wave * 4096 + (32 * i + OIVAE_ROW(r, hh)) * 64 + 32 * j + l31] = acc[i][j][r];
-    __syncthreads();
-  };
-  stage_acc(dW2a);
-  {
-    float* dst = a.gW2 + cs + (int64_t)g * DG * M;
-    for (int idx = tid; idx < 4096; idx += 256)
-      dst[idx] = ((stage[idx] + stage[4096 + idx]) + stage[2 * 4096 + idx]) + stage[3 * 4096 + idx];
-  }
-  stage_acc(Pa);
-  float* sP = sAf;   // A's two copies and W2 are dead: P, W1 take their places
-  float* uW1 = sW2;
-  float* uWs = sAct + 4 * 4096;
-  for (int idx = tid; idx < 4096; idx += 256) {
-    const int o = (idx >> 6) * LW + (idx & 63);
-    sP[o] = ((stage[idx] + stage[4096 + idx]) + stage[2 * 4096 + idx]) + stage[3 * 4096 + idx];
-    uW1[o] = W1g[idx];
-    uWs[o] = Wsg[idx];
-  }
-  __syncthreads();
-  {
-    const int it = wave >> 1, ht = wave & 1;
-    f32x16 acc = (f32x16)(0.f);  // dW1[m][h] = sum_k P[m][k] Ws[k][h]
-    const float* pa = sP + (32 * it + l31) * LW + hh;
-    const float* pb = uWs + hh * LW + 32 * ht + l31;
-#pragma unroll 8
-    for (int s = 0; s < 32; ++s) acc = mf32(pa[2 * s], pb[2 * s * LW], acc);
-    float* d1 = a.gW1 + cs + (int64_t)g * M * H;
+        for (int q = 0; q < 2; ++q) x3mm(dW2a[i][j], gNf[i][q], tNf[j][q]);
+    // ---- dt = W2^T gmu, both orientations; da1 = dt (1 - t^2) ----
+    f32x16 dT[2], dN[2];
+    Frag3 df[4], dNf[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) d1[(32 * it + OIVAE_ROW(r, hh)) * H + 32 * ht + l31] = acc[r];
-    acc = (f32x16)(0.f);         // dWs[k][h] = sum_m P[m][k] W1[m][h]
-    pa = sP + hh * LW + 32 * it + l31;
-    pb = uW1 + hh * LW + 32 * ht + l31;
-#pragma unroll 8
-    for (int s = 0; s < 32; ++s) acc = mf32(pa[2 * s * LW], pb[2 * s * LW], acc);
-    float* d2 = a.gWs + cs + (int64_t)g * K * H;
+    for (int rb = 0; rb < 2; ++rb) {
+      dT[rb] = (f32x16)(0.f);
+      dN[rb] = (f32x16)(0.f);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) d2[(32 * it + OIVAE_ROW(r, hh)) * H + 32 * ht + l31] = acc[r];
+      for (int ks = 0; ks < 4; ++ks) {
+        const Frag3 w = wfrag(3, rb, ks);
+        x3mm(dT[rb], w, gf[ks]);
+        x3mm(dN[rb], gf[ks], w);
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dT[rb][r] *= tT[rb][r];
+        dN[rb][r] *= tN[rb][r];
+        s += dN[rb][r];
+      }
+      sd1[rb] += s;
+      df[2 * rb] = afrag(dT[rb], 0); df[2 * rb + 1] = afrag(dT[rb], 1);
+      dNf[rb][0] = afrag(dN[rb], 0); dNf[rb][1] = afrag(dN[rb], 1);
+    }
+    // ---- P[m][k] += sum_n da1[n][m] z[n][k] ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) x3mm(Pa[i][j], dNf[i][q], zNf[j][q]);
+    // ---- dz^T[k][n] += sum_m A[m][k] da1[n][m] ----
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 dz = (f32x16)(0.f);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) x3mm(dz, wfrag(1, kb, ks), df[ks]);
+      if (r0 + l31 < N32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(a.dzT + (int64_t)(32 * kb + OIVAE_ROW(r, hh)) * a.N + nT, dz[r]);
+      }
+    }
   }
-  stage[wave * 192 + lane] = cs_gmu;
-  stage[wave * 192 + 64 + lane] = cs_gmu2;
-  stage[wave * 192 + 128 + lane] = cs_da1;
+  // per-column sums: the two lane halves of a column are added through LDS, lane L then holds column L
+  __syncthreads();  // every wave is done with the staging area's previous contents (the images stay untouched)
+  float* tmp = scr + 2 * 64 * LW + wave * 384;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    tmp[(0 * 2 + b) * 64 + hh * 32 + l31] = sg1[b];
+    tmp[(1 * 2 + b) * 64 + hh * 32 + l31] = sg2[b];
+    tmp[(2 * 2 + b) * 64 + hh * 32 + l31] = sd1[b];
+  }
   __syncthreads();
-  float* sred = stage + 1024;
-  if (tid < 64) {
-    const float s_gmu = ((stage[tid] + stage[192 + tid]) + stage[384 + tid]) + stage[576 + tid];
-    const float s_gmu2 = ((stage[64 + tid] + stage[256 + tid]) + stage[448 + tid]) + stage[640 + tid];
-    const float s_da1 = ((stage[128 + tid] + stage[320 + tid]) + stage[512 + tid]) + stage[704 + tid];
-    const int64_t d = (int64_t)g * DG + tid;
-    const float e = expf(a.ls[d]);
-    const float sg = e + a.sig_off;
-    const float c2 = a.inv / sg;
-    const float sumq2 = s_gmu2 / (c2 * c2);
-    const float nrows = (chunk == 0) ? (float)a.N : 0.f;
-    a.gb2[cs + d] = s_gmu;
-    a.gls[cs + d] = (nrows - sumq2) * (e * a.inv / sg);
-    a.gb1[cs + (int64_t)g * M + tid] = s_da1;
-    sred[tid] = nrows * (-0.5f * kLog2Pi - logf(sg)) - 0.5f * sumq2;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double tot = 0.0;
-    for (int i = 0; i < 64; ++i) tot += (double)sred[i];
-    a.ll_part[(int64_t)chunk * gridDim.x + g] = tot;
-  }
+  const int cb = lane >> 5;
+  const float cs_gmu = tmp[(0 * 2 + cb) * 64 + l31] + tmp[(0 * 2 + cb) * 64 + 32 + l31];
+  const float cs_gmu2 = tmp[(1 * 2 + cb) * 64 + l31] + tmp[(1 * 2 + cb) * 64 + 32 + l31];
+  const float cs_da1 = tmp[(2 * 2 + cb) * 64 + l31] + tmp[(2 * 2 + cb) * 64 + 32 + l31];
+  // the images are dead: staging for the four-wave reduction; P and W1 go to the fp32 staging slots
+  dec64_finish(a, g, chunk, tid, wave, lane, dW2a, Pa, cs_gmu, cs_gmu2, cs_da1, reinterpret_cast<float*>(img), scr, scr + 64 * LW);
 }
+
 
 bool mfma_decoder_applies(const oivae_shape_t& s) {
   if (getenv("OIVAE_FORCE_GENERIC")) return false;  // test hook: cross-check the two kernel families
@@ -951,8 +1258,16 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   int rc;
   // OIVAE_DEC=v1 (test hook) selects the layer-by-layer template kernel for the all-64 shape, which also serves
   // launches whose dz image exceeds the 32-bit byte offsets of dec_mfma64_v4's atomics (N*K*4 >= 2^32)
-  const bool force_v1 = getenv("OIVAE_DEC") != nullptr;
-  if (s.K == 64 && !force_v1 && N * (int64_t)s.K * 4 < (int64_t)1 << 32) {
+  const char* dec_env = getenv("OIVAE_DEC");
+  const bool force_v1 = dec_env != nullptr && dec_env[0] == 'v';
+  const bool use_x3 = dec_env != nullptr && dec_env[0] == 'x';
+  if (s.K == 64 && use_x3) {
+    OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_x3_64),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kX3DecLds));
+    hipLaunchKernelGGL(dec_x3_64, dim3((unsigned)s.G, (unsigned)chunks), dim3(256), (size_t)kX3DecLds, st, a);
+    OIVAE_LAUNCH_CHECK();
+    rc = OIVAE_OK;
+  } else if (s.K == 64 && !force_v1 && N * (int64_t)s.K * 4 < (int64_t)1 << 32) {
     const size_t lds = (size_t)(3 * 64 * 65 + 4 * 64 + 4 * 3 * 32 * 68) * sizeof(float);
     OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_mfma64_v4),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

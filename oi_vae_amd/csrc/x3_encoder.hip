@@ -21,40 +21,18 @@
 // image laid out the way LDS wants it.  Roofline: 6/16 of the fp32 MFMA time, which at
 // the scale-up shape puts both GEMMs at the HBM time of reading X once.
 #include "common.h"
+#include "x3_split.h"
 
 #include <stdlib.h>
 
 namespace oivae {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using f32x16 = x3_f32x16;
+using f32x4 = x3_f32x4;
+using u32x4 = x3_u32x4;
 using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 #define OIVAE_ROW(r, hh) (((r) & 3) + 8 * ((r) >> 2) + 4 * (hh))
-
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {  // low half = bf16(a), high half = bf16(b), RNE
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-// (a, b) -> packed bf16 pairs of the three terms
-struct Split3 { uint32_t h, m, l; };
-__device__ __forceinline__ Split3 split_pair(float a, float b) {
-  Split3 r;
-  r.h = cvt_pk_bf16(a, b);
-  const float ra = a - __uint_as_float(r.h << 16), rb = b - __uint_as_float(r.h & 0xffff0000u);
-  r.m = cvt_pk_bf16(ra, rb);
-  const float sa = ra - __uint_as_float(r.m << 16), sb = rb - __uint_as_float(r.m & 0xffff0000u);
-  r.l = cvt_pk_bf16(sa, sb);
-  return r;
-}
-
-__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 
 // six partial products of one 32x32x16 step; fa/fb = {hi, mid, lo}
 template <int NI, int NJ>

@@ -1,0 +1,59 @@
+// fp32 operands as three bf16 terms for v_mfma_f32_32x32x16_bf16 (gfx950): shared by x3_encoder.hip and the
+// x3 decoder kernel.  x = hi + mid + lo exactly (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), RNE);
+// a product of two such operands is accumulated in fp32 from the six partial products of weight >= 2^-16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace oivae {
+
+using x3_f32x16 = __attribute__((ext_vector_type(16))) float;
+using x3_f32x4 = __attribute__((ext_vector_type(4))) float;
+using x3_u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using x3_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {  // low half = bf16(a), high half = bf16(b), RNE
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// (a, b) -> packed bf16 pairs of the three terms
+struct Split3 { uint32_t h, m, l; };
+__device__ __forceinline__ Split3 split_pair(float a, float b) {
+  Split3 r;
+  r.h = cvt_pk_bf16(a, b);
+  const float ra = a - __uint_as_float(r.h << 16), rb = b - __uint_as_float(r.h & 0xffff0000u);
+  r.m = cvt_pk_bf16(ra, rb);
+  const float sa = ra - __uint_as_float(r.m << 16), sb = rb - __uint_as_float(r.m & 0xffff0000u);
+  r.l = cvt_pk_bf16(sa, sb);
+  return r;
+}
+
+// one MFMA operand (8 reduction slots per lane) in its three terms
+struct Frag3 { x3_u32x4 p[3]; };
+
+__device__ __forceinline__ Frag3 split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+  const Split3 a = split_pair(v0, v1), b = split_pair(v2, v3), c = split_pair(v4, v5), d = split_pair(v6, v7);
+  Frag3 f;
+  f.p[0] = x3_u32x4{a.h, b.h, c.h, d.h};
+  f.p[1] = x3_u32x4{a.m, b.m, c.m, d.m};
+  f.p[2] = x3_u32x4{a.l, b.l, c.l, d.l};
+  return f;
+}
+
+__device__ __forceinline__ x3_f32x16 mfma_bf16(x3_u32x4 a, x3_u32x4 b, x3_f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3_bf16x8, a), __builtin_bit_cast(x3_bf16x8, b), c, 0, 0, 0);
+}
+
+// acc += A * B over 16 reduction slots: the six partial products, small terms first
+__device__ __forceinline__ void x3mm(x3_f32x16& acc, const Frag3& A, const Frag3& B) {
+  acc = mfma_bf16(A.p[2], B.p[0], acc);
+  acc = mfma_bf16(A.p[0], B.p[2], acc);
+  acc = mfma_bf16(A.p[1], B.p[1], acc);
+  acc = mfma_bf16(A.p[1], B.p[0], acc);
+  acc = mfma_bf16(A.p[0], B.p[1], acc);
+  acc = mfma_bf16(A.p[0], B.p[0], acc);
+}
+
+}  // namespace oivae
