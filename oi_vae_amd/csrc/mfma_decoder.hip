@@ -907,14 +907,13 @@ __global__ __launch_bounds__(256) void dec_mfma64_v4(MfmaDecArgs a) {
 // MFMA time).  Same mathematics as dec_mfma64_v4 (composed first layer A = W1 Ws^T), different data flow:
 //   * weights sit in LDS as MFMA-ready split images (one 1 KB fragment per (row block, 16 reduction slots, term)):
 //     kC A (rows m), A^T (rows k), W2 (rows d), W2^T (rows m);
-//   * every activation is computed in BOTH orientations, transposed (lane = batch row, registers = features:
-//     the accumulator is the next layer's operand after a split in registers) and plain (lane = feature,
-//     registers = batch rows: the accumulator is, after the same split, the operand of the weight-gradient
-//     products, whose reduction runs over batch rows).  The same operand registers serve both -- only the
-//     A/B roles of the MFMA swap -- so the duplicates cost matrix instructions (7 + 2 products instead of
-//     4 + 2) but no LDS round trip, no transposition and no workgroup barrier in the row loop;
-//   * column sums (db1, db2, sum of squares for log-lik and dlog_sigma) are plain per-lane adds in the
-//     feature-on-lane orientation.
+//   * the chain runs transposed as in v4 (lane = batch row, registers = features: an accumulator becomes the next
+//     layer's operand after a split in registers); for the weight-gradient products, whose reduction runs over
+//     batch rows, each activation takes a wave-private LDS round trip as fp32 ([row][feature] tile written 16 bytes
+//     at a time, read back with lane = feature) and is split again in that orientation; no workgroup barrier in
+//     the row loop;
+//   * column sums (db1, db2, sum of squares for log-lik and dlog_sigma) are plain per-lane adds on the values
+//     read back in the feature-on-lane orientation.
 // The reduction slot order of a chained operand follows the accumulator layout: slot e of lane half hh in step
 // ks is feature 16 ks + 8 (e / 4) + 4 hh + e % 4; the weight images are built in that order.
 // ------------------------------------------------------------------------------------------------------------
@@ -1024,148 +1023,133 @@ __global__ __launch_bounds__(256) void dec_x3_64(MfmaDecArgs a) {
   const int N32 = (int)a.N;
   const int ntiles = (N32 + 31) / 32;
   const bool one_sample = (a.N == a.B);
+  // wave-private [32 rows][68] fp32 tile in the (idle during the row loop) staging area: every activation is
+  // computed in the transposed orientation (lane = batch row), written here 16 bytes at a time and read back in
+  // the plain one (lane = feature, registers = batch rows) for the weight-gradient products and the column sums
+  constexpr int LT = 68;
+  float* tr = scr + wave * (32 * LT);
+  float* trw = tr + l31 * LT + 4 * hh;                 // this lane's row
+  const float* trr = tr + (4 * hh) * LT + l31;         // plain orientation: register r <-> row OIVAE_ROW(r, hh)
+  auto tr_write = [&](const f32x16& v, int rb) {       // accumulator block rb (features 32 rb + OIVAE_ROW(r, hh))
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<f32x4*>(trw + 32 * rb + 8 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+  };
+  auto tr_read = [&](int cb) {                         // column block cb: 16 rows of column 32 cb + l31
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = trr[(8 * (r >> 2) + (r & 3)) * LT + 32 * cb];
+    return v;
+  };
   for (int tile = chunk * 4 + wave; tile < ntiles; tile += 4 * nchunks) {
     const int r0 = tile * 32;
-    const bool full = (r0 + 32 <= N32);
-    const int nT = (r0 + l31 < N32) ? r0 + l31 : N32 - 1;   // this lane's batch row in the transposed orientation
+    const int nT = (r0 + l31 < N32) ? r0 + l31 : N32 - 1;   // this lane's batch row
     const float liveT = (r0 + l31 < N32) ? 1.0f : 0.0f;
-    auto row_n = [&](int r) { const int n = r0 + OIVAE_ROW(r, hh); return n < N32 ? n : N32 - 1; };  // plain orientation
-    auto xrow = [&](int n) { return one_sample ? (int64_t)n : (int64_t)n % a.B; };
+    const float* zp = a.z + (int64_t)nT * K + 4 * hh;
+    const float* xT = a.X + (one_sample ? (int64_t)nT : (int64_t)nT % a.B) * (int64_t)a.D + (int64_t)g * DG + 4 * hh;
 
-    // ---- z in both orientations ----
+    // ---- z: operand of the first product, and (through LDS) of the last ----
     Frag3 zf[4], zNf[2][2];
-    {
-      const float* zp = a.z + (int64_t)nT * K + 4 * hh;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(zp + 16 * ks), v1 = *reinterpret_cast<const f32x4*>(zp + 16 * ks + 8);
-        zf[ks] = split8(v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]);
-      }
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        f32x16 zn;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zn[r] = a.z[(int64_t)row_n(r) * K + 32 * kb + l31];
-        zNf[kb][0] = afrag(zn, 0);
-        zNf[kb][1] = afrag(zn, 1);
-      }
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(zp + 16 * ks), v1 = *reinterpret_cast<const f32x4*>(zp + 16 * ks + 8);
+      *reinterpret_cast<f32x4*>(trw + 16 * ks) = v0;
+      *reinterpret_cast<f32x4*>(trw + 16 * ks + 8) = v1;
+      zf[ks] = split8(v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]);
     }
-    // ---- kC (a1 + b1), both orientations; t = tanh ----
-    f32x16 tT[2], tN[2];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-      init_t(tT[rb], sb1, rb);
-      const float bn = sb1[32 * rb + l31];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tN[rb][r] = bn;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const Frag3 w = wfrag(0, rb, ks);
-        x3mm(tT[rb], w, zf[ks]);
-        x3mm(tN[rb], zf[ks], w);
-      }
+    for (int kb = 0; kb < 2; ++kb) {
+      const f32x16 zn = tr_read(kb);
+      zNf[kb][0] = afrag(zn, 0);
+      zNf[kb][1] = afrag(zn, 1);
     }
+    // ---- kC (a1 + b1); t = tanh; afterwards only 1 - t^2 stays in the accumulators ----
+    f32x16 uT[2];
     Frag3 tf[4], tNf[2][2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
+      init_t(uT[rb], sb1, rb);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        tT[rb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(tT[rb][r]) + 1.0f);
-        tN[rb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(tN[rb][r]) + 1.0f);
-      }
-      tf[2 * rb] = afrag(tT[rb], 0); tf[2 * rb + 1] = afrag(tT[rb], 1);
-      tNf[rb][0] = afrag(tN[rb], 0); tNf[rb][1] = afrag(tN[rb], 1);
+      for (int ks = 0; ks < 4; ++ks) x3mm(uT[rb], wfrag(0, rb, ks), zf[ks]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {  // from here on only 1 - t^2 is needed
-        tT[rb][r] = 1.0f - tT[rb][r] * tT[rb][r];
-        tN[rb][r] = 1.0f - tN[rb][r] * tN[rb][r];
-      }
+      for (int r = 0; r < 16; ++r) uT[rb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(uT[rb][r]) + 1.0f);
+      tr_write(uT[rb], rb);
+      tf[2 * rb] = afrag(uT[rb], 0); tf[2 * rb + 1] = afrag(uT[rb], 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) uT[rb][r] = 1.0f - uT[rb][r] * uT[rb][r];
     }
-    // ---- mu, both orientations; gmu = (mu - x) inv / sigma^2 ----
-    f32x16 gT[2], gN[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const f32x16 tn = tr_read(mb);
+      tNf[mb][0] = afrag(tn, 0);
+      tNf[mb][1] = afrag(tn, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- mu = W2 t + b2; gmu = (mu - x) inv / sigma^2 ----
+    Frag3 gf[4];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
-      init_t(gT[rb], sb2, rb);
-      const float bn = sb2[32 * rb + l31];
+      f32x16 gT;
+      init_t(gT, sb2, rb);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gN[rb][r] = bn;
+      for (int ks = 0; ks < 4; ++ks) x3mm(gT, wfrag(2, rb, ks), tf[ks]);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const Frag3 w = wfrag(2, rb, ks);
-        x3mm(gT[rb], w, tf[ks]);
-        x3mm(gN[rb], tf[ks], w);
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(xT + 32 * rb + 8 * q);
+        const f32x4 c3 = *reinterpret_cast<const f32x4*>(sC3 + 32 * rb + 8 * q + 4 * hh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gT[4 * q + i] = (gT[4 * q + i] - x[i]) * (c3[i] * liveT);
+      }
+      tr_write(gT, rb);
+      gf[2 * rb] = afrag(gT, 0); gf[2 * rb + 1] = afrag(gT, 1);
+    }
+    // ---- dW2[d][m] += sum_n gmu[n][d] t[n][m]; column sums of gmu ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const f32x16 gn = tr_read(i);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s1 += gn[r]; s2 = fmaf(gn[r], gn[r], s2); }
+      sg1[i] += s1;
+      sg2[i] += s2;
+      const Frag3 g0 = afrag(gn, 0), g1 = afrag(gn, 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        x3mm(dW2a[i][j], g0, tNf[j][0]);
+        x3mm(dW2a[i][j], g1, tNf[j][1]);
       }
     }
-    Frag3 gf[4], gNf[2][2];
-    {
-      const float* xT = a.X + xrow(nT) * (int64_t)a.D + (int64_t)g * DG + 4 * hh;
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        f32x16 c3;
-        init_t(c3, sC3, rb);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 x = *reinterpret_cast<const f32x4*>(xT + 32 * rb + 8 * q);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) gT[rb][4 * q + i] = (gT[rb][4 * q + i] - x[i]) * (c3[4 * q + i] * liveT);
-        }
-        const float cn = sC3[32 * rb + l31];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n = r0 + OIVAE_ROW(r, hh);
-          const float x = a.X[xrow(n < N32 ? n : N32 - 1) * (int64_t)a.D + (int64_t)g * DG + 32 * rb + l31];
-          float v = (gN[rb][r] - x) * cn;
-          if (!full) v = (n < N32) ? v : 0.f;
-          gN[rb][r] = v;
-          s1 += v;
-          s2 = fmaf(v, v, s2);
-        }
-        sg1[rb] += s1;
-        sg2[rb] += s2;
-        gf[2 * rb] = afrag(gT[rb], 0); gf[2 * rb + 1] = afrag(gT[rb], 1);
-        gNf[rb][0] = afrag(gN[rb], 0); gNf[rb][1] = afrag(gN[rb], 1);
-      }
-    }
-    // ---- dW2[d][m] += sum_n gmu[n][d] t[n][m] ----
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) x3mm(dW2a[i][j], gNf[i][q], tNf[j][q]);
-    // ---- dt = W2^T gmu, both orientations; da1 = dt (1 - t^2) ----
-    f32x16 dT[2], dN[2];
-    Frag3 df[4], dNf[2][2];
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- dt = W2^T gmu; da1 = dt (1 - t^2) ----
+    Frag3 df[4];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
-      dT[rb] = (f32x16)(0.f);
-      dN[rb] = (f32x16)(0.f);
+      f32x16 dT = (f32x16)(0.f);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const Frag3 w = wfrag(3, rb, ks);
-        x3mm(dT[rb], w, gf[ks]);
-        x3mm(dN[rb], gf[ks], w);
-      }
-      float s = 0.f;
+      for (int ks = 0; ks < 4; ++ks) x3mm(dT, wfrag(3, rb, ks), gf[ks]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        dT[rb][r] *= tT[rb][r];
-        dN[rb][r] *= tN[rb][r];
-        s += dN[rb][r];
-      }
-      sd1[rb] += s;
-      df[2 * rb] = afrag(dT[rb], 0); df[2 * rb + 1] = afrag(dT[rb], 1);
-      dNf[rb][0] = afrag(dN[rb], 0); dNf[rb][1] = afrag(dN[rb], 1);
+      for (int r = 0; r < 16; ++r) dT[r] *= uT[rb][r];
+      tr_write(dT, rb);
+      df[2 * rb] = afrag(dT, 0); df[2 * rb + 1] = afrag(dT, 1);
     }
-    // ---- P[m][k] += sum_n da1[n][m] z[n][k] ----
+    // ---- P[m][k] += sum_n da1[n][m] z[n][k]; column sums of da1 ----
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+      const f32x16 dn = tr_read(i);
+      float sd = 0.f;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int r = 0; r < 16; ++r) sd += dn[r];
+      sd1[i] += sd;
+      const Frag3 d0 = afrag(dn, 0), d1 = afrag(dn, 1);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) x3mm(Pa[i][j], dNf[i][q], zNf[j][q]);
+      for (int j = 0; j < 2; ++j) {
+        x3mm(Pa[i][j], d0, zNf[j][0]);
+        x3mm(Pa[i][j], d1, zNf[j][1]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- dz^T[k][n] += sum_m A[m][k] da1[n][m] ----
+    float* dzp = a.dzT + (int64_t)(4 * hh) * a.N + nT;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 dz = (f32x16)(0.f);
@@ -1173,9 +1157,10 @@ __global__ __launch_bounds__(256) void dec_x3_64(MfmaDecArgs a) {
       for (int ks = 0; ks < 4; ++ks) x3mm(dz, wfrag(1, kb, ks), df[ks]);
       if (r0 + l31 < N32) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(a.dzT + (int64_t)(32 * kb + OIVAE_ROW(r, hh)) * a.N + nT, dz[r]);
+        for (int r = 0; r < 16; ++r) atomicAdd(dzp + (int64_t)(32 * kb + 8 * (r >> 2) + (r & 3)) * a.N, dz[r]);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
   // per-column sums: the two lane halves of a column are added through LDS, lane L then holds column L
   __syncthreads();  // every wave is done with the staging area's previous contents (the images stay untouched)
