@@ -102,6 +102,7 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
   w->slab = reinterpret_cast<float*>(take(plan.chunks > 1 ? sizeof(float) * L.total * plan.chunks : 0));
   w->flat = reinterpret_cast<float*>(take(plan.flat ? sizeof(float) * flat_decoder_floats(s, N, nullptr) : 0));
   w->x3_img = reinterpret_cast<uint32_t*>(take(x3_encoder_ws_bytes(s, B)));
+  w->x3_z = reinterpret_cast<uint32_t*>(take((plan.mfma && s.K == 64) ? ((N + 31) / 32) * 24 * 1024 : 0));
   w->total_bytes = off;
   if (p && bytes < off)
     return fail(OIVAE_E_WORKSPACE, "workspace too small: %lld < %lld bytes", (long long)bytes, (long long)off);

@@ -46,6 +46,7 @@ struct Workspace {
   float*  slab;         int32_t n_chunks;  // [n_chunks, P_dec] decoder grad partials (n_chunks > 1)
   int64_t p_dec;                           // floats per decoder-grad slab
   float*  flat;                            // flat (many-small-groups) decoder: Hc | Wc | Wk | Ct | dz partials
+  uint32_t* x3_z;                          // x3 decoder: split image of z, 24 KB per 32 rows
   uint32_t* x3_img;                        // x3 encoder: split image of the weights (fwd) / of dpre (bwd)
   int64_t total_bytes;
 };

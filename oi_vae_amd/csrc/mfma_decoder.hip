@@ -53,6 +53,7 @@ struct MfmaDecArgs {
   float inv;       // 1/(S*B)
   float sig_off;
   double* ll_part;
+  const uint32_t* zimg;  // dec_x3_64: split image of z (x3_split_z), else unused
 };
 
 __device__ __forceinline__ float fast_tanh(float x) {
@@ -921,6 +922,36 @@ constexpr int kX3DecLds = (4 * 6144 + 192 + 3 * 64 * 65) * 4;  // images | b1, b
 
 __device__ __forceinline__ int x3_slot_feature(int ks, int hh, int e) { return 16 * ks + 8 * (e >> 2) + 4 * hh + (e & 3); }
 
+// Split image of z for dec_x3_64, shared by all groups: per 32-row tile 24 fragments of 1 KB,
+//   [0..11]  (ks, term): transposed orientation, lane (row l31, half hh), slot e <-> latent x3_slot_feature(ks, hh, e)
+//   [12..23] (kb, q, term): plain orientation, lane (latent 32 kb + l31, half hh), slot e <-> row 16 q + 8 (e/4) + 4 hh + e%4
+// rows past N repeat row N-1 (the decoder zeroes their gradients).
+__global__ __launch_bounds__(256) void x3_split_z(const float* __restrict__ z, int64_t N, uint32_t* __restrict__ img) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t tiles = (N + 31) / 32;
+  if (i >= tiles * 512) return;
+  const int64_t tile = i >> 9;
+  const int grp = (int)(i >> 6) & 7, lane = (int)i & 63, l31 = lane & 31, hh = lane >> 5;
+  float v[8];
+  if (grp < 4) {
+    int64_t n = tile * 32 + l31;
+    n = n < N ? n : N - 1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = z[n * 64 + x3_slot_feature(grp, hh, e)];
+  } else {
+    const int kb = (grp - 4) >> 1, q = (grp - 4) & 1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int64_t n = tile * 32 + 16 * q + 8 * (e >> 2) + 4 * hh + (e & 3);
+      n = n < N ? n : N - 1;
+      v[e] = z[n * 64 + 32 * kb + l31];
+    }
+  }
+  const Frag3 f = split8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) *reinterpret_cast<x3_u32x4*>(img + ((tile * 24 + grp * 3 + p) * 64 + lane) * 4) = f.p[p];
+}
+
 __global__ __launch_bounds__(256) void dec_x3_64(MfmaDecArgs a) {
   constexpr int K = 64, H = 64, M = 64, DG = 64, LW = 65;
   constexpr float kC = 2.885390081777927f;  // 2*log2(e): tanh(x) = 1 - 2/(exp2(kC x) + 1)
@@ -1045,24 +1076,19 @@ __global__ __launch_bounds__(256) void dec_x3_64(MfmaDecArgs a) {
     const int r0 = tile * 32;
     const int nT = (r0 + l31 < N32) ? r0 + l31 : N32 - 1;   // this lane's batch row
     const float liveT = (r0 + l31 < N32) ? 1.0f : 0.0f;
-    const float* zp = a.z + (int64_t)nT * K + 4 * hh;
     const float* xT = a.X + (one_sample ? (int64_t)nT : (int64_t)nT % a.B) * (int64_t)a.D + (int64_t)g * DG + 4 * hh;
 
-    // ---- z: operand of the first product, and (through LDS) of the last ----
-    Frag3 zf[4], zNf[2][2];
+    // ---- z: its split fragments come ready-made from the image every group shares ----
+    const uint32_t* zi = a.zimg + ((int64_t)tile * 24 * 64 + lane) * 4;
+    auto zfrag = [&](int f) {
+      Frag3 r;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(zp + 16 * ks), v1 = *reinterpret_cast<const f32x4*>(zp + 16 * ks + 8);
-      *reinterpret_cast<f32x4*>(trw + 16 * ks) = v0;
-      *reinterpret_cast<f32x4*>(trw + 16 * ks + 8) = v1;
-      zf[ks] = split8(v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]);
-    }
+      for (int p = 0; p < 3; ++p) r.p[p] = *reinterpret_cast<const x3_u32x4*>(zi + (f * 3 + p) * 256);
+      return r;
+    };
+    Frag3 zf[4];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const f32x16 zn = tr_read(kb);
-      zNf[kb][0] = afrag(zn, 0);
-      zNf[kb][1] = afrag(zn, 1);
-    }
+    for (int ks = 0; ks < 4; ++ks) zf[ks] = zfrag(ks);
     // ---- kC (a1 + b1); t = tanh; afterwards only 1 - t^2 stays in the accumulators ----
     f32x16 uT[2];
     Frag3 tf[4], tNf[2][2];
@@ -1143,8 +1169,8 @@ __global__ __launch_bounds__(256) void dec_x3_64(MfmaDecArgs a) {
       const Frag3 d0 = afrag(dn, 0), d1 = afrag(dn, 1);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        x3mm(Pa[i][j], d0, zNf[j][0]);
-        x3mm(Pa[i][j], d1, zNf[j][1]);
+        x3mm(Pa[i][j], d0, zfrag(4 + 2 * j));
+        x3mm(Pa[i][j], d1, zfrag(4 + 2 * j + 1));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1240,6 +1266,7 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   a.inv = 1.0f / ((float)S * (float)B);
   a.sig_off = gen_sig_off;
   a.ll_part = w.ll_part;
+  a.zimg = nullptr;
   int rc;
   // OIVAE_DEC=v1 (test hook) selects the layer-by-layer template kernel for the all-64 shape, which also serves
   // launches whose dz image exceeds the 32-bit byte offsets of dec_mfma64_v4's atomics (N*K*4 >= 2^32)
@@ -1247,6 +1274,11 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   const bool force_v1 = dec_env != nullptr && dec_env[0] == 'v';
   const bool use_x3 = dec_env != nullptr && dec_env[0] == 'x';
   if (s.K == 64 && use_x3) {
+    if (!w.x3_z) return fail(OIVAE_E_WORKSPACE, "x3 decoder: no z image in the workspace");
+    const int64_t zt = (N + 31) / 32;
+    hipLaunchKernelGGL(x3_split_z, dim3((unsigned)((zt * 512 + 255) / 256)), dim3(256), 0, st, z, N, w.x3_z);
+    OIVAE_LAUNCH_CHECK();
+    a.zimg = w.x3_z;
     OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_x3_64),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kX3DecLds));
     hipLaunchKernelGGL(dec_x3_64, dim3((unsigned)s.G, (unsigned)chunks), dim3(256), (size_t)kX3DecLds, st, a);
