@@ -1271,8 +1271,10 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   // OIVAE_DEC=v1 (test hook) selects the layer-by-layer template kernel for the all-64 shape, which also serves
   // launches whose dz image exceeds the 32-bit byte offsets of dec_mfma64_v4's atomics (N*K*4 >= 2^32)
   const char* dec_env = getenv("OIVAE_DEC");
-  const bool force_v1 = dec_env != nullptr && dec_env[0] == 'v';
-  const bool use_x3 = dec_env != nullptr && dec_env[0] == 'x';
+  // test hooks: OIVAE_DEC=v1 the layer-by-layer fp32 template kernel, OIVAE_DEC=v4 the fp32 composed-first-layer
+  // kernel; default for the all-64 shape: dec_x3_64
+  const bool force_v1 = dec_env != nullptr && dec_env[0] == 'v' && dec_env[1] == '1';
+  const bool use_x3 = dec_env == nullptr || dec_env[0] == 'x';
   if (s.K == 64 && use_x3) {
     if (!w.x3_z) return fail(OIVAE_E_WORKSPACE, "x3 decoder: no z image in the workspace");
     const int64_t zt = (N + 31) / 32;

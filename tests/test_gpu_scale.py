@@ -52,17 +52,20 @@ def test_mfma_kernels_agree_with_generic_kernels(tmp_path):
   script = tmp_path / "cross.py"
   script.write_text(_CROSS % {"root": ROOT})
   res = {}
-  for mode in ("mfma", "generic", "layerwise"):
+  for mode in ("mfma", "generic", "layerwise", "fp32"):
     env = dict(os.environ)
     if mode == "generic":
       env["OIVAE_FORCE_GENERIC"] = "1"
     if mode == "layerwise":
-      env["OIVAE_DEC"] = "v1"   # the nine-product template kernel instead of the composed-first-layer one
+      env["OIVAE_DEC"] = "v1"   # the nine-product fp32 template kernel
+    if mode == "fp32":
+      env["OIVAE_DEC"] = "v4"   # the fp32-MFMA composed-first-layer kernel instead of the split-bf16 one
+      env["OIVAE_ENC"] = "fp32"
     out = tmp_path / (mode + ".npz")
     subprocess.run([sys.executable, str(script), mode, str(out)], check=True, env=env, timeout=300)
     res[mode] = np.load(out)
   eng = _engine(24, 64, 64, 64, 64, seed=1)  # segment-wise comparison relative to each tensor's scale
-  for other in ("generic", "layerwise"):
+  for other in ("generic", "layerwise", "fp32"):
     a, b = res["mfma"], res[other]
     assert np.max(np.abs(a["sc"][:6] - b["sc"][:6]) / np.maximum(np.abs(b["sc"][:6]), 1)) < 1e-5, other
     assert np.array_equal(a["z"], b["z"]) or np.max(np.abs(a["z"] - b["z"])) < 1e-5

@@ -11,10 +11,7 @@ from tests.test_gpu_scale import _engine  # noqa: E402
 
 
 def setmode(m):
-  if m == "v4":
-    os.environ.pop("OIVAE_DEC", None)
-  else:
-    os.environ["OIVAE_DEC"] = m
+  os.environ["OIVAE_DEC"] = m
 
 
 def agree():
