@@ -1072,23 +1072,35 @@ __global__ __launch_bounds__(256) void dec_x3_64(MfmaDecArgs a) {
     for (int r = 0; r < 16; ++r) v[r] = trr[(8 * (r >> 2) + (r & 3)) * LT + 32 * cb];
     return v;
   };
-  for (int tile = chunk * 4 + wave; tile < ntiles; tile += 4 * nchunks) {
+  // z's split fragments come ready-made from the image every group shares.  Global-memory latency is never waited
+  // for in the row loop: a tile's transposed-orientation fragments are fetched during the previous tile, its
+  // plain-orientation ones and its x rows at the top of the tile, two and four products ahead of their use.
+  auto zfrag_of = [&](int t, int f) {
+    Frag3 r;
+    const uint32_t* zi = a.zimg + ((int64_t)t * 24 * 64 + lane) * 4;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) r.p[p] = *reinterpret_cast<const x3_u32x4*>(zi + (f * 3 + p) * 256);
+    return r;
+  };
+  int tile = chunk * 4 + wave;
+  Frag3 zf[4];
+  if (tile < ntiles) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) zf[ks] = zfrag_of(tile, ks);
+  }
+  for (; tile < ntiles; tile += 4 * nchunks) {
     const int r0 = tile * 32;
     const int nT = (r0 + l31 < N32) ? r0 + l31 : N32 - 1;   // this lane's batch row
     const float liveT = (r0 + l31 < N32) ? 1.0f : 0.0f;
     const float* xT = a.X + (one_sample ? (int64_t)nT : (int64_t)nT % a.B) * (int64_t)a.D + (int64_t)g * DG + 4 * hh;
-
-    // ---- z: its split fragments come ready-made from the image every group shares ----
-    const uint32_t* zi = a.zimg + ((int64_t)tile * 24 * 64 + lane) * 4;
-    auto zfrag = [&](int f) {
-      Frag3 r;
+    const int tnext = (tile + 4 * nchunks < ntiles) ? tile + 4 * nchunks : tile;
+    auto zfrag = [&](int f) { return zfrag_of(tile, f); };
+    f32x4 xq[2][4];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) r.p[p] = *reinterpret_cast<const x3_u32x4*>(zi + (f * 3 + p) * 256);
-      return r;
-    };
-    Frag3 zf[4];
+    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) zf[ks] = zfrag(ks);
+      for (int q = 0; q < 4; ++q) xq[rb][q] = *reinterpret_cast<const f32x4*>(xT + 32 * rb + 8 * q);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- kC (a1 + b1); t = tanh; afterwards only 1 - t^2 stays in the accumulators ----
     f32x16 uT[2];
     Frag3 tf[4], tNf[2][2];
@@ -1111,6 +1123,12 @@ __global__ __launch_bounds__(256) void dec_x3_64(MfmaDecArgs a) {
       tNf[mb][1] = afrag(tn, 1);
     }
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) zf[ks] = zfrag_of(tnext, ks);   // the next tile's first operand
+    Frag3 zn[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) zn[f] = zfrag(4 + f);              // this tile's last operand
+    __builtin_amdgcn_sched_barrier(0);
     // ---- mu = W2 t + b2; gmu = (mu - x) inv / sigma^2 ----
     Frag3 gf[4];
 #pragma unroll
@@ -1121,7 +1139,7 @@ __global__ __launch_bounds__(256) void dec_x3_64(MfmaDecArgs a) {
       for (int ks = 0; ks < 4; ++ks) x3mm(gT, wfrag(2, rb, ks), tf[ks]);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(xT + 32 * rb + 8 * q);
+        const f32x4 x = xq[rb][q];
         const f32x4 c3 = *reinterpret_cast<const f32x4*>(sC3 + 32 * rb + 8 * q + 4 * hh);
 #pragma unroll
         for (int i = 0; i < 4; ++i) gT[4 * q + i] = (gT[4 * q + i] - x[i]) * (c3[i] * liveT);
@@ -1169,8 +1187,8 @@ __global__ __launch_bounds__(256) void dec_x3_64(MfmaDecArgs a) {
       const Frag3 d0 = afrag(dn, 0), d1 = afrag(dn, 1);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        x3mm(Pa[i][j], d0, zfrag(4 + 2 * j));
-        x3mm(Pa[i][j], d1, zfrag(4 + 2 * j + 1));
+        x3mm(Pa[i][j], d0, zn[2 * j]);
+        x3mm(Pa[i][j], d1, zn[2 * j + 1]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
