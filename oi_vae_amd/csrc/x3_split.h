@@ -12,28 +12,17 @@ using x3_f32x4 = __attribute__((ext_vector_type(4))) float;
 using x3_u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 using x3_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {  // low half = bf16(a), high half = bf16(b), RNE
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+// low half = bf16(a), high half = bf16(b), round to nearest even: one v_cvt_pk_bf16_f32.  Written as a vector
+// conversion, not inline asm, so that the compiler knows the instruction (hazards against the MFMAs that read it).
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 // (a, b) -> packed bf16 pairs of the three terms
 struct Split3 { uint32_t h, m, l; };
-#ifdef OIVAE_X3_PK
-using x3_f32x2 = __attribute__((ext_vector_type(2))) float;
-__device__ __forceinline__ Split3 split_pair(float a, float b) {
-  Split3 r;
-  r.h = cvt_pk_bf16(a, b);
-  x3_f32x2 v = {a, b}, h = {__uint_as_float(r.h << 16), __uint_as_float(r.h & 0xffff0000u)};
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(v) : "v"(v), "v"(h));
-  r.m = cvt_pk_bf16(v[0], v[1]);
-  h = x3_f32x2{__uint_as_float(r.m << 16), __uint_as_float(r.m & 0xffff0000u)};
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(v) : "v"(v), "v"(h));
-  r.l = cvt_pk_bf16(v[0], v[1]);
-  return r;
-}
-#else
 __device__ __forceinline__ Split3 split_pair(float a, float b) {
   Split3 r;
   r.h = cvt_pk_bf16(a, b);
@@ -43,7 +32,6 @@ __device__ __forceinline__ Split3 split_pair(float a, float b) {
   r.l = cvt_pk_bf16(sa, sb);
   return r;
 }
-#endif
 
 // one MFMA operand (8 reduction slots per lane) in its three terms
 struct Frag3 { x3_u32x4 p[3]; };
