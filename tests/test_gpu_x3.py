@@ -127,3 +127,54 @@ def test_x3_path_is_deterministic():
   a = _encoder_fwd(eng, X, eps)
   b = _encoder_fwd(eng, X, eps)
   assert torch.equal(a, b)
+
+
+def test_decoder_gradients_are_fp32_grade():
+  """oivae_decoder_fwd_bwd_f32 at the all-64 generator shape (dec_x3_64 by default, dec_mfma64_v4 under OIVAE_DEC=v4)
+  against float64 autograd of -loglik / (S B) on the same fp32 inputs: ragged row count, two samples per row."""
+  from oi_vae_amd import Engine, ModelSpec, _lib
+  G, K, B, S = 6, 64, 150, 2
+  D, N = G * 64, B * S
+  eng = Engine(ModelSpec(D=D, K=K, H=64, M=64, group_dims=[64] * G, gen_type="mlp"), device="cuda:0")
+  g = torch.Generator(device="cuda").manual_seed(21)
+  for n in ("gen_W1", "gen_b1", "gen_W2", "gen_b2"):
+    eng.p[n].copy_((torch.rand(eng.p[n].shape, generator=g, device="cuda") * 2 - 1) / 8)
+  eng.p["log_sigma"].copy_(torch.rand(eng.p["log_sigma"].shape, generator=g, device="cuda") * 0.5 - 1.5)
+  eng.p["Ws"].copy_(torch.randn(eng.p["Ws"].shape, generator=g, device="cuda") * 0.3)
+  X = torch.rand(B, D, generator=g, device="cuda")
+  z = torch.randn(N, K, generator=g, device="cuda")
+
+  # float64 reference (lib/models.py:91-95, lib/distributions.py:40-45, lib/oivae.py:55-59)
+  p64 = {n: eng.p[n].double().clone().requires_grad_(True) for n in ("gen_W1", "gen_b1", "gen_W2", "gen_b2", "log_sigma", "Ws")}
+  z64 = z.double().clone().requires_grad_(True)
+  W1 = p64["gen_W1"].view(G, 64, 64); b1 = p64["gen_b1"].view(G, 64)
+  W2 = p64["gen_W2"].view(G, 64, 64); b2 = p64["gen_b2"].view(G, 64)
+  h = torch.einsum("nk,gkh->gnh", z64, p64["Ws"].view(G, K, 64))
+  a1 = torch.einsum("gnh,gmh->gnm", h, W1) + b1[:, None, :]
+  mu = torch.einsum("gnm,gdm->gnd", torch.tanh(a1), W2) + b2[:, None, :]
+  sig = torch.exp(p64["log_sigma"].view(G, 64)) + 1e-3
+  x = X.double().repeat(S, 1).view(N, G, 64).permute(1, 0, 2)
+  ll = (-0.5 * np.log(2 * np.pi) - torch.log(sig)[:, None, :] - 0.5 * ((x - mu) / sig[:, None, :]) ** 2).sum()
+  (-ll / (S * B)).backward()
+  want = {n: p64[n].grad.cpu() for n in p64}
+  want_dz = z64.grad.cpu()
+
+  err = {}
+  for mode in ("v4", "x3"):
+    os.environ["OIVAE_DEC"] = mode
+    eng._ws_key = None
+    ws = eng._workspace(B, S)
+    eng.flat_grads.fill_(float("nan"))
+    dz = torch.empty(K, N, device="cuda")      # the matrix-core decoders hand dz over transposed
+    _lib.check(eng.lib.oivae_decoder_fwd_bwd_f32(ctypes.byref(eng._shape), ctypes.byref(eng._pt), ctypes.byref(eng._gt),
+               X.data_ptr(), B, S, z.data_ptr(), 1e-3, dz.data_ptr(), ws.data_ptr(), eng._ws_bytes, eng._stream()), "decoder")
+    torch.cuda.synchronize()
+    e = {"dz": float((dz.t().double().cpu() - want_dz).abs().max() / want_dz.abs().max())}
+    for n in want:
+      got = eng.g[n].double().cpu().view_as(want[n])
+      e[n] = float((got - want[n]).abs().max() / want[n].abs().max())
+    err[mode] = e
+  os.environ.pop("OIVAE_DEC", None)
+  for n in err["x3"]:
+    assert err["x3"][n] <= 5e-6, (n, err)
+    assert err["x3"][n] <= 1.5 * err["v4"][n] + 3e-7, (n, err)
