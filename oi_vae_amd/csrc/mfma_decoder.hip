@@ -985,20 +985,18 @@ __global__ __launch_bounds__(256) void dec_x3_64(MfmaDecArgs a) {
       sC3[tid] = (a.inv / sg) / sg;
     }
     __syncthreads();
-    // A[m][k] = sum_h W1[m][h] Ws[k][h] (fp32 fma chain), 16 entries per thread, then in place of W1
-    float av[16];
+    // A[m][k] = sum_h W1[m][h] Ws[k][h] on the fp32 matrix instruction (an fmaf chain, as in dec_mfma64_v4): one
+    // 32 x 32 block per wave, then in place of W1
+    {
+      const int mt = wave >> 1, kt = wave & 1;
+      f32x16 acc = (f32x16)(0.f);
+      const float* pa = tW1 + (32 * mt + l31) * LW + hh;
+      const float* pb = tWs + (32 * kt + l31) * LW + hh;
+#pragma unroll 8
+      for (int s2 = 0; s2 < 32; ++s2) acc = mf32(pa[2 * s2], pb[2 * s2], acc);
+      __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int idx = tid + 256 * i, m = idx >> 6, k = idx & 63;
-      float acc = 0.f;
-      for (int h = 0; h < 64; ++h) acc = fmaf(tW1[m * LW + h], tWs[k * LW + h], acc);
-      av[i] = acc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int idx = tid + 256 * i;
-      tW1[(idx >> 6) * LW + (idx & 63)] = av[i];
+      for (int r = 0; r < 16; ++r) tW1[(32 * mt + OIVAE_ROW(r, hh)) * LW + 32 * kt + l31] = acc[r];
     }
     __syncthreads();
     const float* A = tW1;
