@@ -89,13 +89,15 @@ __global__ __launch_bounds__(256) void x3_split_rows(const float* __restrict__ W
 //   waves 8-11  W producers: the weight image from L2, four tiles ahead, copied to LDS.  (Loads return in order per
 //               wave: in one queue the L2 hits would wait behind the HBM loads.)
 // The producers' VALU/LDS/VMEM instructions issue in the shadow of the consumers' MFMAs (tools/probe/mfma_probe3).
-// LDS holds two macro tiles (112 KB); ONE barrier per macro tile: before it the consumers have read tile t into
+// LDS holds two macro tiles (113 KB); ONE barrier per macro tile: before it the consumers have read tile t into
 // registers and the producers have written tile t+1, after it the consumers' remaining MFMAs of tile t run from
 // registers while tile t+1 is read, so no LDS latency is exposed either.
 // LDS row r of sub-step s = 28 dwords: piece p at +8p, lane-half h at +4h (8 bf16 = one MFMA operand).
 // ------------------------------------------------------------------------------
 constexpr int kX3Row = 28;                      // dwords per LDS row: 24 + 4 pad (28*l mod 64: 16 distinct multiples of 4)
-constexpr int kX3Buf = 4 * 128 * kX3Row;        // dwords per macro tile: X [2][128][28] | W [2][128][28]
+constexpr int kX3Sub = 128 * kX3Row + 32;         // one sub-step of one operand; +32 dwords so that the two sub-steps a
+                                                 // producer store straddles fall on opposite halves of the 64 banks
+constexpr int kX3Buf = 4 * kX3Sub;              // dwords per macro tile: X [2][kX3Sub] | W [2][kX3Sub]
 constexpr int kX3StagesX = 4;                   // X macro tiles in flight per producer
 constexpr int kX3StagesW = 4;
 
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(768, 1) void enc_x3_gemm(const float* __restrict__ 
       const int f = tid + 256 * i, row = f / 12, ch = f % 12;
       const int s = ch / 6, p = (ch % 6) >> 1, h = ch & 1;
       wptr[i] = Wimg + ((int64_t)(j0 + row) * KT + (kbeg >> 5)) * 48 + 4 * ch;
-      woff[i] = 2 * 128 * kX3Row + (s * 128 + row) * kX3Row + 8 * p + 4 * h;
+      woff[i] = 2 * kX3Sub + s * kX3Sub + row * kX3Row + 8 * p + 4 * h;
     }
     u32x4 rw[kX3StagesW][6];
     auto wload = [&](int t, u32x4 (&r)[6]) {
@@ -173,12 +175,12 @@ __global__ __launch_bounds__(768, 1) void enc_x3_gemm(const float* __restrict__ 
         const int64_t row = m0 + xr + 32 * i;
         xptr[i] = X + (row < B ? row : B - 1) * (int64_t)D + kbeg + 4 * xc;
       }
-      xoff = ((xc >> 2) * 128 + xr) * kX3Row + 4 * ((xc >> 1) & 1) + 2 * (xc & 1);
+      xoff = (xc >> 2) * kX3Sub + xr * kX3Row + 4 * ((xc >> 1) & 1) + 2 * (xc & 1);
     } else {
       const int c = tid & 31, rg = tid >> 5;  // columns d = m0 + 4c..4c+3, rows 4 rg..4 rg+3 of the macro tile
 #pragma unroll
       for (int i = 0; i < 4; ++i) xptr[i] = X + (int64_t)(4 * rg + i) * D + m0 + 4 * c;
-      xoff = ((rg >> 2) * 128 + c) * kX3Row + 4 * ((rg >> 1) & 1) + 2 * (rg & 1);
+      xoff = (rg >> 2) * kX3Sub + c * kX3Row + 4 * ((rg >> 1) & 1) + 2 * (rg & 1);
     }
     const int64_t xstep = BWD ? 32 * (int64_t)D : 32;
     f32x4 rx[kX3StagesX][4];
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(768, 1) void enc_x3_gemm(const float* __restrict__ 
     // ---------------- consumers ----------------
     const int wm = wave >> 1, wn = wave & 1;
     const uint32_t* a0 = lds + (wm * 64 + l31) * kX3Row + 4 * hh;
-    const uint32_t* b0 = lds + 2 * 128 * kX3Row + (wn * 64 + l31) * kX3Row + 4 * hh;
+    const uint32_t* b0 = lds + 2 * kX3Sub + (wn * 64 + l31) * kX3Row + 4 * hh;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -229,8 +231,8 @@ __global__ __launch_bounds__(768, 1) void enc_x3_gemm(const float* __restrict__ 
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-          fa[s][i][p] = *reinterpret_cast<const u32x4*>(a0 + buf * kX3Buf + (s * 128 + 32 * i) * kX3Row + 8 * p);
-          fb[s][i][p] = *reinterpret_cast<const u32x4*>(b0 + buf * kX3Buf + (s * 128 + 32 * i) * kX3Row + 8 * p);
+          fa[s][i][p] = *reinterpret_cast<const u32x4*>(a0 + buf * kX3Buf + s * kX3Sub + 32 * i * kX3Row + 8 * p);
+          fb[s][i][p] = *reinterpret_cast<const u32x4*>(b0 + buf * kX3Buf + s * kX3Sub + 32 * i * kX3Row + 8 * p);
         }
     };
     __syncthreads();  // P_{-1}
