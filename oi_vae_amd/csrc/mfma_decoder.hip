@@ -555,7 +555,9 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a_, f32x2 b_) {
 // db2, dlog_sigma, db1 and the group's log-likelihood partial.  `stage`: >= 4*4096 + 64*65 floats; sP, uW1: 64*65 each.
 __device__ __forceinline__ void dec64_finish(const MfmaDecArgs& a, int g, int chunk, int tid, int wave, int lane,
                                              f32x16 (&dW2a)[2][2], f32x16 (&Pa)[2][2], float cs_gmu, float cs_gmu2,
-                                             float cs_da1, float* stage, float* sP, float* uW1) {
+                                             float cs_da1, float* stage, float* sP, float* uW1, bool act = true) {
+  // `act`: waves that hold partials (all of them in the 4-wave kernels; the weight-gradient waves of dec_x3_64p,
+  // numbered 0..3 with tid 0..255 by the caller); the others only pass the barriers
   constexpr int K = 64, H = 64, M = 64, DG = 64, LW = 65;
   const int l31 = lane & 31, hh = lane >> 5;
   const float* Wsg = a.Ws + (int64_t)g * K * H;
@@ -565,31 +567,33 @@ __device__ __forceinline__ void dec64_finish(const MfmaDecArgs& a, int g, int ch
   const int64_t cs = a.chunk_stride * chunk;
   auto stage_acc = [&](f32x16 (&acc)[2][2]) {
     __syncthreads();
+    if (act) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          stage[wave * 4096 + (32 * i + OIVAE_ROW(r, hh)) * 64 + 32 * j + l31] = acc[i][j][r];
+          for (int r = 0; r < 16; ++r)
+            stage[wave * 4096 + (32 * i + OIVAE_ROW(r, hh)) * 64 + 32 * j + l31] = acc[i][j][r];
+    }
     __syncthreads();
   };
   stage_acc(dW2a);
-  {
+  if (act) {
     float* dst = a.gW2 + cs + (int64_t)g * DG * M;
     for (int idx = tid; idx < 4096; idx += 256)
       dst[idx] = ((stage[idx] + stage[4096 + idx]) + stage[2 * 4096 + idx]) + stage[3 * 4096 + idx];
   }
   stage_acc(Pa);
   float* uWs = stage + 4 * 4096;
-  for (int idx = tid; idx < 4096; idx += 256) {
+  for (int idx = tid; act && idx < 4096; idx += 256) {
     const int o = (idx >> 6) * LW + (idx & 63);
     sP[o] = ((stage[idx] + stage[4096 + idx]) + stage[2 * 4096 + idx]) + stage[3 * 4096 + idx];
     uW1[o] = W1g[idx];
     uWs[o] = Wsg[idx];
   }
   __syncthreads();
-  {
+  if (act) {
     const int it = wave >> 1, ht = wave & 1;
     f32x16 acc = (f32x16)(0.f);  // dW1[m][h] = sum_k P[m][k] Ws[k][h]
     const float* pa = sP + (32 * it + l31) * LW + hh;
@@ -608,12 +612,14 @@ __device__ __forceinline__ void dec64_finish(const MfmaDecArgs& a, int g, int ch
 #pragma unroll
     for (int r = 0; r < 16; ++r) d2[(32 * it + OIVAE_ROW(r, hh)) * H + 32 * ht + l31] = acc[r];
   }
-  stage[wave * 192 + lane] = cs_gmu;
-  stage[wave * 192 + 64 + lane] = cs_gmu2;
-  stage[wave * 192 + 128 + lane] = cs_da1;
+  if (act) {
+    stage[wave * 192 + lane] = cs_gmu;
+    stage[wave * 192 + 64 + lane] = cs_gmu2;
+    stage[wave * 192 + 128 + lane] = cs_da1;
+  }
   __syncthreads();
   float* sred = stage + 1024;
-  if (tid < 64) {
+  if (act && tid < 64) {
     const float s_gmu = ((stage[tid] + stage[192 + tid]) + stage[384 + tid]) + stage[576 + tid];
     const float s_gmu2 = ((stage[64 + tid] + stage[256 + tid]) + stage[448 + tid]) + stage[640 + tid];
     const float s_da1 = ((stage[128 + tid] + stage[320 + tid]) + stage[512 + tid]) + stage[704 + tid];
@@ -629,7 +635,7 @@ __device__ __forceinline__ void dec64_finish(const MfmaDecArgs& a, int g, int ch
     sred[tid] = nrows * (-0.5f * kLog2Pi - logf(sg)) - 0.5f * sumq2;
   }
   __syncthreads();
-  if (tid == 0) {
+  if (act && tid == 0) {
     double tot = 0.0;
     for (int i = 0; i < 64; ++i) tot += (double)sred[i];
     a.ll_part[(int64_t)chunk * gridDim.x + g] = tot;
@@ -1223,6 +1229,333 @@ __global__ __launch_bounds__(256) void dec_x3_64(MfmaDecArgs a) {
 }
 
 
+// ------------------------------------------------------------------------------------------------------------
+// dec_x3_64p: dec_x3_64 with TWO waves per SIMD.  dec_x3_64 is instruction-issue-bound in its single wave per SIMD
+// (2600 instructions per 32-row tile against 288 MFMAs), and its registers (128 persistent accumulators + the chain)
+// and LDS leave no room for a second copy of that wave.  Here the work of one tile stream is split by ROLE instead:
+//   chain wave  (waves 0-3): the four chained products, tanh / gmu / da1, the splits in the transposed orientation,
+//                            the dz atomics; publishes t, gmu and da1 as fp32 tiles in the stream's LDS tile;
+//   weight-gradient wave (waves 4-7, same stream = wave & 3): reads each tile back with lane = feature, column sums,
+//                            splits in that orientation, dW2 += gmu^T t and P += da1^T z with the 128 persistent
+//                            accumulators.
+// Each role fits 256 registers, the LDS footprint is unchanged, and the two issue streams of a SIMD interleave in
+// hardware (one wave's vector work under the other's MFMAs).  Hand-over through two counters per stream in LDS
+// (tiles published / tiles consumed, single buffer): a wave's LDS instructions complete in order, so "write tile,
+// s_waitcnt lgkmcnt(0), bump counter" and "see counter, read tile" need no barrier; every wait loop is bounded.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kX3DecLdsP = kX3DecLds + 64;
+
+__device__ __forceinline__ void lds_wait_ge(const volatile uint32_t* f, uint32_t v) {
+  int guard = 0;
+  while (__builtin_amdgcn_readfirstlane(*f) < v && ++guard < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void lds_post(volatile uint32_t* f, uint32_t v) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's tile accesses are done
+  *f = v;
+}
+
+__global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
+  constexpr int K = 64, H = 64, M = 64, DG = 64, LW = 65;
+  constexpr float kC = 2.885390081777927f;  // 2*log2(e): tanh(x) = 1 - 2/(exp2(kC x) + 1)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint32_t* img = reinterpret_cast<uint32_t*>(smem_raw);   // [4][2 rb][4 ks][3 terms][64 lanes][4 dwords]
+  float* sb1 = reinterpret_cast<float*>(img + 4 * 6144);   // kC * b1
+  float* sb2 = sb1 + 64;
+  float* sC3 = sb2 + 64;                                   // inv / sigma_d^2
+  float* scr = sC3 + 64;                                   // 3 x [64][65] fp32 staging
+  volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(scr + 3 * 64 * LW);  // [4 streams][published, consumed]
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int g = blockIdx.x, chunk = blockIdx.y, nchunks = gridDim.y;
+  const bool chainw = wave < 4;
+  const int sw = wave & 3;
+  {
+    float* tW1 = scr;
+    float* tWs = scr + 64 * LW;
+    float* tW2 = scr + 2 * 64 * LW;
+    const float* Wsg = a.Ws + (int64_t)g * K * H;
+    const float* W1g = a.W1 + (int64_t)g * M * H;
+    const float* W2g = a.W2 + (int64_t)g * DG * M;
+    for (int i = tid; i < 4096; i += 512) {
+      const int o = (i >> 6) * LW + (i & 63);
+      tW1[o] = W1g[i];
+      tWs[o] = Wsg[i];
+      tW2[o] = W2g[i];
+    }
+    if (tid < 64) {
+      const float sg = expf(a.ls[(int64_t)g * DG + tid]) + a.sig_off;
+      sb1[tid] = kC * a.b1[(int64_t)g * M + tid];
+      sb2[tid] = a.b2[(int64_t)g * DG + tid];
+      sC3[tid] = (a.inv / sg) / sg;
+    }
+    if (tid < 16) flags[tid] = 0;
+    __syncthreads();
+    // A[m][k] = sum_h W1[m][h] Ws[k][h] on the fp32 matrix instruction, one 32 x 32 block per chain wave
+    f32x16 acc = (f32x16)(0.f);
+    const int mt = sw >> 1, kt = sw & 1;
+    if (chainw) {
+      const float* pa = tW1 + (32 * mt + l31) * LW + hh;
+      const float* pb = tWs + (32 * kt + l31) * LW + hh;
+#pragma unroll 8
+      for (int s2 = 0; s2 < 32; ++s2) acc = mf32(pa[2 * s2], pb[2 * s2], acc);
+    }
+    __syncthreads();
+    if (chainw) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tW1[(32 * mt + OIVAE_ROW(r, hh)) * LW + 32 * kt + l31] = acc[r];
+    }
+    __syncthreads();
+    const float* A = tW1;
+    {  // the four split images: item = (row r, step ks, lane half h2) -> 8 slots -> three 16-byte terms; 512 items
+      const int item = tid;
+      const int r = item >> 3, ks = (item >> 1) & 3, h2 = item & 1;
+      float v[4][8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = x3_slot_feature(ks, h2, e);
+        v[0][e] = kC * A[r * LW + c];
+        v[1][e] = A[c * LW + r];
+        v[2][e] = tW2[r * LW + c];
+        v[3][e] = tW2[c * LW + r];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const Frag3 f = split8(v[q][0], v[q][1], v[q][2], v[q][3], v[q][4], v[q][5], v[q][6], v[q][7]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          *reinterpret_cast<x3_u32x4*>(img + q * 6144 + ((((r >> 5) * 4 + ks) * 3 + p) * 64 + h2 * 32 + (r & 31)) * 4) = f.p[p];
+      }
+    }
+    __syncthreads();
+  }
+  const uint32_t* imgl = img + lane * 4;
+  auto wfrag = [&](int which, int rb, int ks) {
+    Frag3 f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) f.p[p] = *reinterpret_cast<const x3_u32x4*>(imgl + which * 6144 + ((rb * 4 + ks) * 3 + p) * 256);
+    return f;
+  };
+  auto afrag = [&](const f32x16& v, int q) {
+    return split8(v[8 * q], v[8 * q + 1], v[8 * q + 2], v[8 * q + 3], v[8 * q + 4], v[8 * q + 5], v[8 * q + 6], v[8 * q + 7]);
+  };
+  auto init_t = [&](f32x16& acc, const float* vec, int rb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(vec + 32 * rb + 8 * q + 4 * hh);
+      acc[4 * q] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
+    }
+  };
+  auto zfrag_of = [&](int t, int f) {
+    Frag3 r;
+    const uint32_t* zi = a.zimg + ((int64_t)t * 24 * 64 + lane) * 4;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) r.p[p] = *reinterpret_cast<const x3_u32x4*>(zi + (f * 3 + p) * 256);
+    return r;
+  };
+  // the stream's fp32 tile [32 rows][68]: written 16 bytes at a time with lane = batch row, read with lane = feature
+  constexpr int LT = 68;
+  float* tr = scr + sw * (32 * LT);
+  float* trw = tr + l31 * LT + 4 * hh;
+  const float* trr = tr + (4 * hh) * LT + l31;
+  auto tr_write = [&](const f32x16& v, int rb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<f32x4*>(trw + 32 * rb + 8 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+  };
+  auto tr_read = [&](int cb) {
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = trr[(8 * (r >> 2) + (r & 3)) * LT + 32 * cb];
+    return v;
+  };
+  volatile uint32_t* f_pub = flags + 2 * sw;
+  volatile uint32_t* f_con = flags + 2 * sw + 1;
+
+  const int N32 = (int)a.N;
+  const int ntiles = (N32 + 31) / 32;
+  const bool one_sample = (a.N == a.B);
+  f32x16 dW2a[2][2], Pa[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { dW2a[i][j] = (f32x16)(0.f); Pa[i][j] = (f32x16)(0.f); }
+  float sg1[2] = {0.f, 0.f}, sg2[2] = {0.f, 0.f}, sd1[2] = {0.f, 0.f};
+
+  if (chainw) {
+    // =============================== chain wave ===============================
+    uint32_t pub = 0;
+    Frag3 zf[4];
+    if (chunk * 4 + sw < ntiles) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) zf[ks] = zfrag_of(chunk * 4 + sw, ks);
+    }
+    for (int tile = chunk * 4 + sw; tile < ntiles; tile += 4 * nchunks) {
+      const int tnext = (tile + 4 * nchunks < ntiles) ? tile + 4 * nchunks : tile;
+      const int r0 = tile * 32;
+      const int nT = (r0 + l31 < N32) ? r0 + l31 : N32 - 1;
+      const float liveT = (r0 + l31 < N32) ? 1.0f : 0.0f;
+      const float* xT = a.X + (one_sample ? (int64_t)nT : (int64_t)nT % a.B) * (int64_t)a.D + (int64_t)g * DG + 4 * hh;
+      // ---- kC (a1 + b1); z's fragments were fetched during the previous tile, x is needed two products from here ----
+      f32x4 xq[2][4];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xq[rb][q] = *reinterpret_cast<const f32x4*>(xT + 32 * rb + 8 * q);
+      f32x16 uT[2];
+      init_t(uT[0], sb1, 0);
+      init_t(uT[1], sb1, 1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        x3mm(uT[0], wfrag(0, 0, ks), zf[ks]);
+        x3mm(uT[1], wfrag(0, 1, ks), zf[ks]);
+      }
+      // ---- t = tanh: published first, split afterwards ----
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) uT[rb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(uT[rb][r]) + 1.0f);
+      lds_wait_ge(f_con, pub);
+      tr_write(uT[0], 0);
+      tr_write(uT[1], 1);
+      lds_post(f_pub, ++pub);
+      Frag3 tf[4];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        tf[2 * rb] = afrag(uT[rb], 0); tf[2 * rb + 1] = afrag(uT[rb], 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) uT[rb][r] = 1.0f - uT[rb][r] * uT[rb][r];
+      }
+      // ---- mu = W2 t + b2; gmu = (mu - x) inv / sigma^2 ----
+      f32x16 gT[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        init_t(gT[rb], sb2, rb);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x3mm(gT[rb], wfrag(2, rb, ks), tf[ks]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 c3 = *reinterpret_cast<const f32x4*>(sC3 + 32 * rb + 8 * q + 4 * hh);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) gT[rb][4 * q + i] = (gT[rb][4 * q + i] - xq[rb][q][i]) * (c3[i] * liveT);
+        }
+      }
+      lds_wait_ge(f_con, pub);
+      tr_write(gT[0], 0);
+      tr_write(gT[1], 1);
+      lds_post(f_pub, ++pub);
+      Frag3 gf[4];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) { gf[2 * rb] = afrag(gT[rb], 0); gf[2 * rb + 1] = afrag(gT[rb], 1); }
+      // ---- dt = W2^T gmu; da1 = dt (1 - t^2) ----
+      f32x16 dT[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        dT[rb] = (f32x16)(0.f);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x3mm(dT[rb], wfrag(3, rb, ks), gf[ks]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dT[rb][r] *= uT[rb][r];
+      }
+      lds_wait_ge(f_con, pub);
+      tr_write(dT[0], 0);
+      tr_write(dT[1], 1);
+      lds_post(f_pub, ++pub);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) zf[ks] = zfrag_of(tnext, ks);   // the next tile's first operand, one product ahead
+      Frag3 df[4];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) { df[2 * rb] = afrag(dT[rb], 0); df[2 * rb + 1] = afrag(dT[rb], 1); }
+      // ---- dz^T[k][n] += sum_m A[m][k] da1[n][m] ----
+      float* dzp = a.dzT + (int64_t)(4 * hh) * a.N + nT;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16 dz = (f32x16)(0.f);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x3mm(dz, wfrag(1, kb, ks), df[ks]);
+        if (r0 + l31 < N32) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) atomicAdd(dzp + (int64_t)(32 * kb + 8 * (r >> 2) + (r & 3)) * a.N, dz[r]);
+        }
+      }
+    }
+  } else {
+    // =============================== weight-gradient wave ===============================
+    uint32_t seen = 0;
+    for (int tile = chunk * 4 + sw; tile < ntiles; tile += 4 * nchunks) {
+      f32x16 rd[2];
+      Frag3 tNf[2][2];
+      // ---- t ----
+      lds_wait_ge(f_pub, seen + 1);
+      rd[0] = tr_read(0);
+      rd[1] = tr_read(1);
+      lds_post(f_con, ++seen);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) { tNf[mb][0] = afrag(rd[mb], 0); tNf[mb][1] = afrag(rd[mb], 1); }
+      // ---- gmu: column sums, dW2[d][m] += sum_n gmu[n][d] t[n][m] ----
+      lds_wait_ge(f_pub, seen + 1);
+      rd[0] = tr_read(0);
+      rd[1] = tr_read(1);
+      lds_post(f_con, ++seen);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1 += rd[i][r]; s2 = fmaf(rd[i][r], rd[i][r], s2); }
+        sg1[i] += s1;
+        sg2[i] += s2;
+        const Frag3 g0 = afrag(rd[i], 0), g1 = afrag(rd[i], 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          x3mm(dW2a[i][j], g0, tNf[j][0]);
+          x3mm(dW2a[i][j], g1, tNf[j][1]);
+        }
+      }
+      // ---- da1: column sums, P[m][k] += sum_n da1[n][m] z[n][k] (z's fragments requested before the wait) ----
+      Frag3 zn[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) zn[f] = zfrag_of(tile, 4 + f);
+      lds_wait_ge(f_pub, seen + 1);
+      rd[0] = tr_read(0);
+      rd[1] = tr_read(1);
+      lds_post(f_con, ++seen);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float sd = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sd += rd[i][r];
+        sd1[i] += sd;
+        const Frag3 d0 = afrag(rd[i], 0), d1 = afrag(rd[i], 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          x3mm(Pa[i][j], d0, zn[2 * j]);
+          x3mm(Pa[i][j], d1, zn[2 * j + 1]);
+        }
+      }
+    }
+  }
+  // per-column sums: the two lane halves of a column are added through LDS, lane L then holds column L
+  __syncthreads();
+  float* tmp = scr + 2 * 64 * LW + sw * 384;
+  if (!chainw) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      tmp[(0 * 2 + b) * 64 + hh * 32 + l31] = sg1[b];
+      tmp[(1 * 2 + b) * 64 + hh * 32 + l31] = sg2[b];
+      tmp[(2 * 2 + b) * 64 + hh * 32 + l31] = sd1[b];
+    }
+  }
+  __syncthreads();
+  const int cb = lane >> 5;
+  const float cs_gmu = tmp[(0 * 2 + cb) * 64 + l31] + tmp[(0 * 2 + cb) * 64 + 32 + l31];
+  const float cs_gmu2 = tmp[(1 * 2 + cb) * 64 + l31] + tmp[(1 * 2 + cb) * 64 + 32 + l31];
+  const float cs_da1 = tmp[(2 * 2 + cb) * 64 + l31] + tmp[(2 * 2 + cb) * 64 + 32 + l31];
+  dec64_finish(a, g, chunk, tid & 255, sw, lane, dW2a, Pa, cs_gmu, cs_gmu2, cs_da1, reinterpret_cast<float*>(img), scr,
+               scr + 64 * LW, !chainw);
+}
+
+
 bool mfma_decoder_applies(const oivae_shape_t& s) {
   if (getenv("OIVAE_FORCE_GENERIC")) return false;  // test hook: cross-check the two kernel families
   if (s.gen_type != OIVAE_GEN_MLP) return false;
@@ -1288,18 +1621,25 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   // launches whose dz image exceeds the 32-bit byte offsets of dec_mfma64_v4's atomics (N*K*4 >= 2^32)
   const char* dec_env = getenv("OIVAE_DEC");
   // test hooks: OIVAE_DEC=v1 the layer-by-layer fp32 template kernel, OIVAE_DEC=v4 the fp32 composed-first-layer
-  // kernel; default for the all-64 shape: dec_x3_64
+  // kernel, OIVAE_DEC=x3 the single-wave-per-SIMD split-bf16 kernel; default for the all-64 shape: dec_x3_64p
   const bool force_v1 = dec_env != nullptr && dec_env[0] == 'v' && dec_env[1] == '1';
-  const bool use_x3 = dec_env == nullptr || dec_env[0] == 'x';
+  const bool use_x3 = dec_env == nullptr || dec_env[0] == 'x' || dec_env[0] == 'p';
+  const bool use_pair = dec_env == nullptr || dec_env[0] == 'p';
   if (s.K == 64 && use_x3) {
     if (!w.x3_z) return fail(OIVAE_E_WORKSPACE, "x3 decoder: no z image in the workspace");
     const int64_t zt = (N + 31) / 32;
     hipLaunchKernelGGL(x3_split_z, dim3((unsigned)((zt * 512 + 255) / 256)), dim3(256), 0, st, z, N, w.x3_z);
     OIVAE_LAUNCH_CHECK();
     a.zimg = w.x3_z;
-    OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_x3_64),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kX3DecLds));
-    hipLaunchKernelGGL(dec_x3_64, dim3((unsigned)s.G, (unsigned)chunks), dim3(256), (size_t)kX3DecLds, st, a);
+    if (use_pair) {
+      OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_x3_64p),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kX3DecLdsP));
+      hipLaunchKernelGGL(dec_x3_64p, dim3((unsigned)s.G, (unsigned)chunks), dim3(512), (size_t)kX3DecLdsP, st, a);
+    } else {
+      OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_x3_64),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kX3DecLds));
+      hipLaunchKernelGGL(dec_x3_64, dim3((unsigned)s.G, (unsigned)chunks), dim3(256), (size_t)kX3DecLds, st, a);
+    }
     OIVAE_LAUNCH_CHECK();
     rc = OIVAE_OK;
   } else if (s.K == 64 && !force_v1 && N * (int64_t)s.K * 4 < (int64_t)1 << 32) {

@@ -130,7 +130,8 @@ def test_x3_path_is_deterministic():
 
 
 def test_decoder_gradients_are_fp32_grade():
-  """oivae_decoder_fwd_bwd_f32 at the all-64 generator shape (dec_x3_64 by default, dec_mfma64_v4 under OIVAE_DEC=v4)
+  """oivae_decoder_fwd_bwd_f32 at the all-64 generator shape (dec_x3_64p by default, dec_x3_64 under OIVAE_DEC=x3, dec_mfma64_v4 under
+  OIVAE_DEC=v4)
   against float64 autograd of -loglik / (S B) on the same fp32 inputs: ragged row count, two samples per row."""
   from oi_vae_amd import Engine, ModelSpec, _lib
   G, K, B, S = 6, 64, 150, 2
@@ -160,8 +161,9 @@ def test_decoder_gradients_are_fp32_grade():
   want_dz = z64.grad.cpu()
 
   err = {}
-  for mode in ("v4", "x3"):
+  for mode in ("v4", "x3", "default"):
     os.environ["OIVAE_DEC"] = mode
+    if mode == "default": os.environ.pop("OIVAE_DEC")
     eng._ws_key = None
     ws = eng._workspace(B, S)
     eng.flat_grads.fill_(float("nan"))
@@ -175,6 +177,7 @@ def test_decoder_gradients_are_fp32_grade():
       e[n] = float((got - want[n]).abs().max() / want[n].abs().max())
     err[mode] = e
   os.environ.pop("OIVAE_DEC", None)
-  for n in err["x3"]:
-    assert err["x3"][n] <= 5e-6, (n, err)
-    assert err["x3"][n] <= 1.5 * err["v4"][n] + 3e-7, (n, err)
+  for mode in ("x3", "default"):
+    for n in err[mode]:
+      assert err[mode][n] <= 5e-6, (mode, n, err)
+      assert err[mode][n] <= 1.5 * err["v4"][n] + 3e-7, (mode, n, err)
