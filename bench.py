@@ -54,7 +54,7 @@ def decoder_executed_flops(rows):
 
 
 def decoder_bf16_flops(rows):
-  """bf16 matrix flops dec_x3_64 issues in the row loop: each of the six fp32 products becomes six bf16
+  """bf16 matrix flops dec_x3_64p issues in the row loop: each of the six fp32 products becomes six bf16
   products of the split operands: 288 v_mfma_f32_32x32x16_bf16 per 32-row tile and group."""
   return (rows + 31) // 32 * G * 288 * (2 * 32 * 32 * 16)
 
@@ -220,7 +220,7 @@ def main():
       "config": {"workload": "synthetic scale-up: G=1024 groups x 64 dims, K=64, H=M=64 two-layer generators, "
                              "global batch 65536, S=1", "global_batch": GLOBAL_BATCH,
                  "parallelism": "dp%d" % world, "rows_per_gpu": rows},
-      "roofline": {"bound": "mfma", "kernel": "dec_x3_64 (grouped decoder fwd+bwd)",
+      "roofline": {"bound": "mfma", "kernel": "dec_x3_64p (grouped decoder fwd+bwd)",
                    "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic() if world == 1 else None,
                    "avg_launch_ms": dec_avg, "flops_per_launch": dec_flops,
@@ -238,10 +238,10 @@ def main():
                            "vector work of the splits, DESIGN.md 3.1)"},
       "step_model_tflops": (decoder_flops_per_row() + encoder_flops_per_row()) * GLOBAL_BATCH / (ms * 1e-3) / 1e12 / world,
       "entry_ms": {k: sum(v) / len(v) for k, v in per_kernel.items()},
-      "arithmetic": "fp32 in, fp32 out, fp32 accumulation everywhere.  Decoder: v_mfma_f32_32x32x2_f32.  Encoder GEMMs: "
-                    "each fp32 operand carried exactly as three bf16 terms, six bf16 matrix products per fp32 product "
-                    "(x3_encoder.hip); error against float64 no larger than the fp32 matrix instructions' "
-                    "(tests/test_gpu_x3.py); OIVAE_ENC=fp32 selects the fp32 instructions",
+      "arithmetic": "fp32 in, fp32 out, fp32 accumulation everywhere.  Decoder and encoder GEMMs: each fp32 operand "
+                    "carried exactly as three bf16 terms, six v_mfma_f32_32x32x16_bf16 products per fp32 product "
+                    "(x3_split.h); error against float64 no larger than the fp32 matrix instructions' "
+                    "(tests/test_gpu_x3.py); OIVAE_ENC=fp32 OIVAE_DEC=v4 select the fp32 matrix instructions",
     }
     if world == 1:
       out["prox_roofline"] = prox_roofline(device)
