@@ -1251,8 +1251,10 @@ __device__ __forceinline__ void lds_wait_ge(const volatile uint32_t* f, uint32_t
   asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void lds_post(volatile uint32_t* f, uint32_t v) {
+  __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's tile accesses are done
   *f = v;
+  __builtin_amdgcn_sched_barrier(0);   // or the scheduler sinks the store below the MFMAs that follow: the partner waits
 }
 
 __global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
@@ -1340,6 +1342,25 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
   auto afrag = [&](const f32x16& v, int q) {
     return split8(v[8 * q], v[8 * q + 1], v[8 * q + 2], v[8 * q + 3], v[8 * q + 4], v[8 * q + 5], v[8 * q + 6], v[8 * q + 7]);
   };
+  // One chained product, both 32-row output blocks, as eight pinned units (u = 4 rb + ks) of six MFMAs: the weight
+  // fragments of unit u+2 are requested and the operand of step u+1 is split inside unit u's region, so that LDS
+  // latency and the split's vector work sit under MFMAs already issued (left to itself the scheduler requests a
+  // fragment one MFMA before its use and waits for it).  `side(u)`: independent work to place in unit u.
+  auto chain_mm = [&](f32x16* acc, int which, Frag3* bf, auto&& make, auto&& side) {
+    Frag3 w[3];
+    w[0] = wfrag(which, 0, 0);
+    w[1] = wfrag(which, 0, 1);
+    bf[0] = make(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u + 2 < 8) w[(u + 2) % 3] = wfrag(which, (u + 2) >> 2, (u + 2) & 3);
+      if (u + 1 < 4) bf[u + 1] = make(u + 1);
+      side(u);
+      x3mm(acc[u >> 2], w[u % 3], bf[u & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   auto init_t = [&](f32x16& acc, const float* vec, int rb) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1406,12 +1427,9 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
       f32x16 uT[2];
       init_t(uT[0], sb1, 0);
       init_t(uT[1], sb1, 1);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        x3mm(uT[0], wfrag(0, 0, ks), zf[ks]);
-        x3mm(uT[1], wfrag(0, 1, ks), zf[ks]);
-      }
-      // ---- t = tanh: published first, split afterwards ----
+      auto none = [&](int) {};
+      chain_mm(uT, 0, zf, [&](int ks) { return zf[ks]; }, none);
+      // ---- t = tanh: published first, split during the next product ----
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -1420,64 +1438,70 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
       tr_write(uT[0], 0);
       tr_write(uT[1], 1);
       lds_post(f_pub, ++pub);
+      // ---- mu = W2 t + b2; gmu = (mu - x) inv / sigma^2; afterwards uT holds 1 - t^2 ----
       Frag3 tf[4];
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        tf[2 * rb] = afrag(uT[rb], 0); tf[2 * rb + 1] = afrag(uT[rb], 1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) uT[rb][r] = 1.0f - uT[rb][r] * uT[rb][r];
-      }
-      // ---- mu = W2 t + b2; gmu = (mu - x) inv / sigma^2 ----
       f32x16 gT[2];
+      init_t(gT[0], sb2, 0);
+      init_t(gT[1], sb2, 1);
+      auto gmu_quarter = [&](int rb, int q) {
+        const f32x4 c3 = *reinterpret_cast<const f32x4*>(sC3 + 32 * rb + 8 * q + 4 * hh);
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        init_t(gT[rb], sb2, rb);
+        for (int i = 0; i < 4; ++i) gT[rb][4 * q + i] = (gT[rb][4 * q + i] - xq[rb][q][i]) * (c3[i] * liveT);
+      };
+      chain_mm(gT, 2, tf,
+               [&](int ks) {
+                 const Frag3 f = afrag(uT[ks >> 1], ks & 1);
+                 if (ks & 1) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) x3mm(gT[rb], wfrag(2, rb, ks), tf[ks]);
+                   for (int r = 0; r < 16; ++r) uT[ks >> 1][r] = 1.0f - uT[ks >> 1][r] * uT[ks >> 1][r];
+                 }
+                 return f;
+               },
+               [&](int u) { if (u >= 4) gmu_quarter(0, u - 4); });   // block 0 is complete from unit 4 on
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 c3 = *reinterpret_cast<const f32x4*>(sC3 + 32 * rb + 8 * q + 4 * hh);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) gT[rb][4 * q + i] = (gT[rb][4 * q + i] - xq[rb][q][i]) * (c3[i] * liveT);
-        }
-      }
+      for (int q = 0; q < 4; ++q) gmu_quarter(1, q);
       lds_wait_ge(f_con, pub);
       tr_write(gT[0], 0);
       tr_write(gT[1], 1);
       lds_post(f_pub, ++pub);
-      Frag3 gf[4];
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) { gf[2 * rb] = afrag(gT[rb], 0); gf[2 * rb + 1] = afrag(gT[rb], 1); }
       // ---- dt = W2^T gmu; da1 = dt (1 - t^2) ----
+      Frag3 gf[4];
       f32x16 dT[2];
+      dT[0] = (f32x16)(0.f);
+      dT[1] = (f32x16)(0.f);
+      chain_mm(dT, 3, gf, [&](int ks) { return afrag(gT[ks >> 1], ks & 1); },
+               [&](int u) {
+                 if (u >= 4) {
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        dT[rb] = (f32x16)(0.f);
+                   for (int r = 4 * (u - 4); r < 4 * (u - 4) + 4; ++r) dT[0][r] *= uT[0][r];
+                 }
+               });
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) x3mm(dT[rb], wfrag(3, rb, ks), gf[ks]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dT[rb][r] *= uT[rb][r];
-      }
+      for (int r = 0; r < 16; ++r) dT[1][r] *= uT[1][r];
       lds_wait_ge(f_con, pub);
       tr_write(dT[0], 0);
       tr_write(dT[1], 1);
       lds_post(f_pub, ++pub);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) zf[ks] = zfrag_of(tnext, ks);   // the next tile's first operand, one product ahead
-      Frag3 df[4];
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) { df[2 * rb] = afrag(dT[rb], 0); df[2 * rb + 1] = afrag(dT[rb], 1); }
       // ---- dz^T[k][n] += sum_m A[m][k] da1[n][m] ----
+      Frag3 df[4];
+      f32x16 dz[2];
+      dz[0] = (f32x16)(0.f);
+      dz[1] = (f32x16)(0.f);
       float* dzp = a.dzT + (int64_t)(4 * hh) * a.N + nT;
+      const bool liveRow = r0 + l31 < N32;
+      chain_mm(dz, 1, df, [&](int ks) { return afrag(dT[ks >> 1], ks & 1); },
+               [&](int u) {
+                 if (u >= 4 && liveRow) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        f32x16 dz = (f32x16)(0.f);
+                   for (int r = 4 * (u - 4); r < 4 * (u - 4) + 4; ++r)
+                     atomicAdd(dzp + (int64_t)(8 * (r >> 2) + (r & 3)) * a.N, dz[0][r]);
+                 }
+               });
+      if (liveRow) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) x3mm(dz, wfrag(1, kb, ks), df[ks]);
-        if (r0 + l31 < N32) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) atomicAdd(dzp + (int64_t)(32 * kb + 8 * (r >> 2) + (r & 3)) * a.N, dz[r]);
-        }
+        for (int r = 0; r < 16; ++r) atomicAdd(dzp + (int64_t)(32 + 8 * (r >> 2) + (r & 3)) * a.N, dz[1][r]);
       }
     }
   } else {
