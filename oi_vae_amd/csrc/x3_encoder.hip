@@ -168,7 +168,10 @@ __global__ __launch_bounds__(768, 1) void enc_x3_gemm(const float* __restrict__ 
     const float* xptr[4];
     int xoff;
     if (!BWD) {
-      const int xr = tid >> 3, xc = tid & 7;
+      // rows of a 16-lane group two apart (low two bits of the row index swapped): with consecutive rows the 8-byte
+      // LDS stores of the two sub-steps collide pairwise (64 instead of 32 cycles per store, tools/probe/lds_b128.hip)
+      const int xr0 = tid >> 3, xc = tid & 7;
+      const int xr = (xr0 & ~3) | ((xr0 & 1) << 1) | ((xr0 >> 1) & 1);
       // rows beyond B re-read row B-1 (their results are never stored): no load is conditional
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
