@@ -1406,6 +1406,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
 
   if (chainw) {
     // =============================== chain wave ===============================
+    __builtin_amdgcn_s_setprio(3);   // the critical path of the pair: issue before the other wave of the SIMD
     uint32_t pub = 0;
     Frag3 zf[4];
     if (chunk * 4 + sw < ntiles) {
