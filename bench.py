@@ -28,6 +28,9 @@ GLOBAL_BATCH = 65536
 LR, WS_LR, LAM = 1e-3, 1e-4, 1.0
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 BF16_MATRIX_PEAK_TFLOPS = 16 * 157.3  # dense bf16 = 16 x the fp32 matrix rate, same table
+# what the chip sustains on v_mfma_f32_32x32x16_bf16 alone with random operands (tools/probe/mfma_power.hip: the clock
+# falls from 2.37 to 1.79 GHz at the power limit; with all-zero operands the probe reaches 2445)
+BF16_MATRIX_SUSTAINED_TFLOPS = 1852.0
 
 
 def pmc_traffic():
@@ -230,6 +233,8 @@ def main():
                    "bf16_tflops": decoder_bf16_flops(rows) / (dec_avg * 1e-3) / 1e12 if dec_avg > 0 else 0.0,
                    "bf16_peak": BF16_MATRIX_PEAK_TFLOPS,
                    "bf16_frac": (decoder_bf16_flops(rows) / (dec_avg * 1e-3) / 1e12 / BF16_MATRIX_PEAK_TFLOPS) if dec_avg > 0 else 0.0,
+                   "bf16_sustained_peak": BF16_MATRIX_SUSTAINED_TFLOPS,
+                   "bf16_frac_of_sustained": (decoder_bf16_flops(rows) / (dec_avg * 1e-3) / 1e12 / BF16_MATRIX_SUSTAINED_TFLOPS) if dec_avg > 0 else 0.0,
                    "note": "achieved/peak/frac: the reference algorithm's fp32 flops (9 products per group, SURVEY 8d) "
                            "against the fp32 matrix peak, as in earlier rounds -- above 1 because the kernel composes "
                            "Ws[g] with the generator's first Linear (6 products, executed_*) and issues each fp32 "

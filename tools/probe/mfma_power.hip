@@ -1,0 +1,63 @@
+// Does the bf16 MFMA rate depend on the operand DATA?  All 1024 SIMDs run a chain of v_mfma_f32_32x32x16_bf16 over
+// four accumulators for ~50 ms; operands all zero, or random bf16 values of magnitude ~1.  Reports in-kernel cycles
+// (s_memtime) per MFMA and wall time per MFMA: a power-limited chip lowers its clock under toggling operands.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+__global__ __launch_bounds__(256) void k(const unsigned* in, int iters, float* out, long long* cyc) {
+  u32x4 a[4], b[4];
+  for (int j = 0; j < 4; ++j)
+    for (int e = 0; e < 4; ++e) {
+      a[j][e] = in[(threadIdx.x * 16 + j * 4 + e) & 4095];
+      b[j][e] = in[(threadIdx.x * 16 + j * 4 + e + 2048) & 4095];
+    }
+  f32x16 acc[4];
+  for (int j = 0; j < 4; ++j) acc[j] = (f32x16)(0.f);
+  long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a[(j + s) & 3]), "v"(b[(j + 2 * s) & 3]));
+  }
+  long long t1 = __builtin_amdgcn_s_memtime();
+  float r = 0.f;
+  for (int j = 0; j < 4; ++j)
+    for (int e = 0; e < 16; ++e) r += acc[j][e];
+  out[blockIdx.x * 256 + threadIdx.x] = r;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+int main() {
+  unsigned* in; float* o; long long* c;
+  (void)hipMalloc(&in, 4096 * 4); (void)hipMalloc(&o, 1024 * 256 * 4); (void)hipMalloc(&c, 1024 * 8);
+  unsigned h[4096];
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int mode = 0; mode < 3; ++mode) {
+    srand(1);
+    for (int i = 0; i < 4096; ++i) {
+      if (mode == 0) h[i] = 0;
+      else if (mode == 1) h[i] = 0x3f803f80u;  // 1.0, 1.0: constant non-zero
+      else { unsigned lo = 0x3f00u | (rand() & 0x80ff), hi = 0x3f00u | (rand() & 0x80ff); h[i] = lo | (hi << 16); }  // +-[0.5, 1)
+    }
+    (void)hipMemcpy(in, h, sizeof(h), hipMemcpyHostToDevice);
+    const int iters = 100000;  // 1.6 M MFMAs per wave ~ 30 ms
+    for (int rep = 0; rep < 3; ++rep) {
+      (void)hipEventRecord(e0, 0);
+      hipLaunchKernelGGL(k, dim3(256), dim3(256), 0, 0, in, iters, o, c);
+      (void)hipEventRecord(e1, 0);
+      (void)hipEventSynchronize(e1);
+      float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+      long long hc[256]; (void)hipMemcpy(hc, c, sizeof(hc), hipMemcpyDeviceToHost);
+      double s = 0; for (int i = 0; i < 256; ++i) s += hc[i];
+      const double n = 16.0 * iters;
+      printf("%-22s rep %d: %6.2f counter ticks per MFMA, %6.2f ns per MFMA  (%.0f TFLOP/s bf16 dense, chip-wide)\n",
+             mode == 0 ? "operands all zero" : mode == 1 ? "operands all 1.0" : "operands random", rep, s / 256 / n,
+             ms * 1e6 / n, 1024 * 2.0 * 32 * 32 * 16 / (ms * 1e6 / n) / 1e3);
+    }
+  }
+  return 0;
+}
