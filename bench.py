@@ -239,8 +239,9 @@ def main():
                            "against the fp32 matrix peak, as in earlier rounds -- above 1 because the kernel composes "
                            "Ws[g] with the generator's first Linear (6 products, executed_*) and issues each fp32 "
                            "product as six bf16 matrix products of exactly split operands (bf16_*: the matrix "
-                           "instructions actually issued against the dense bf16 peak; the kernel is bound by the "
-                           "vector work of the splits, DESIGN.md 3.1)"},
+                           "instructions actually issued against the dense bf16 peak, bf16_sustained_peak: what the "
+                           "power-limited chip reaches on that instruction alone with random operands, "
+                           "tools/probe/mfma_power.hip; the kernel is bound by the vector issue port, DESIGN.md 3.0)"},
       "step_model_tflops": (decoder_flops_per_row() + encoder_flops_per_row()) * GLOBAL_BATCH / (ms * 1e-3) / 1e12 / world,
       "entry_ms": {k: sum(v) / len(v) for k, v in per_kernel.items()},
       "arithmetic": "fp32 in, fp32 out, fp32 accumulation everywhere.  Decoder and encoder GEMMs: each fp32 operand "
