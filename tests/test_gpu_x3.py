@@ -181,3 +181,34 @@ def test_decoder_gradients_are_fp32_grade():
     for n in err[mode]:
       assert err[mode][n] <= 5e-6, (mode, n, err)
       assert err[mode][n] <= 1.5 * err["v4"][n] + 3e-7, (mode, n, err)
+
+
+@pytest.mark.parametrize("B,S", [(1, 1), (5, 1), (33, 3), (64, 1), (97, 2)])
+def test_paired_decoder_tiny_batches(B, S):
+  """dec_x3_64p at batches that leave tile streams empty (fewer than four 32-row tiles), end in a ragged tile or
+  repeat rows over samples: same scalars and gradients as the fp32-instruction kernel dec_mfma64_v4."""
+  from tests.test_gpu_scale import _engine
+  G = 5
+  eng = _engine(G, 64, 64, 64, 64, seed=11)
+  g = torch.Generator(device="cuda").manual_seed(100 + B)
+  X = torch.rand(B, G * 64, generator=g, device="cuda")
+  eps = torch.randn(S, B, 64, generator=g, device="cuda")
+  res = {}
+  for mode in ("v4", None):
+    if mode is None:
+      os.environ.pop("OIVAE_DEC", None)
+    else:
+      os.environ["OIVAE_DEC"] = mode
+    eng._ws_key = None
+    out = eng.forward_backward(X, eps, 0.9)
+    torch.cuda.synchronize()
+    res[mode] = (eng.flat_grads.double().cpu().clone(), out["scalars"].double().cpu().clone())
+  os.environ.pop("OIVAE_DEC", None)
+  a, b = res[None], res["v4"]
+  assert torch.isfinite(a[0]).all()
+  assert float(((a[1][:6] - b[1][:6]).abs() / b[1][:6].abs().clamp(min=1.0)).max()) < 1e-5
+  for name in eng.seg_off:
+    o, n = eng.seg_off[name], eng.seg_numel[name]
+    if n:
+      ga, gb = a[0][o:o + n], b[0][o:o + n]
+      assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-12, name
