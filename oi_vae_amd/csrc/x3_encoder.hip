@@ -109,7 +109,8 @@ constexpr int kX3StagesW = 4;
 template <bool BWD>
 __global__ __launch_bounds__(768, 1) void enc_x3_gemm(const float* __restrict__ X, int64_t B, int D, int J,
                                                       const uint32_t* __restrict__ Wimg, int KT,
-                                                      float* __restrict__ out0, float* __restrict__ out1, int klen) {
+                                                      float* __restrict__ out0, float* __restrict__ out1, int klen,
+                                                      uint32_t* __restrict__ rng) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint32_t* lds = reinterpret_cast<uint32_t*>(smem_raw);  // [2][kX3Buf]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -192,10 +193,12 @@ __global__ __launch_bounds__(768, 1) void enc_x3_gemm(const float* __restrict__ 
 #pragma unroll
       for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const f32x4*>(xptr[i] + k0);
     };
+    float xmax = 0.f;  // forward: max |x| seen by this lane, for the fp16 backward kernel's scale
     auto xstore = [&](int buf, const f32x4 (&r)[4]) {
       uint32_t* base = lds + buf * kX3Buf;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        if (!BWD) xmax = fmaxf(fmaxf(xmax, fmaxf(fabsf(r[i][0]), fabsf(r[i][1]))), fmaxf(fabsf(r[i][2]), fabsf(r[i][3])));
         u32x2 P[3];
         // forward: r[i] = 4 consecutive k of row i; backward: column i of 4 consecutive rows (k) -> LDS row 32 i + c
         const Split3 q0 = BWD ? split_pair(r[0][i], r[1][i]) : split_pair(r[i][0], r[i][1]);
@@ -217,6 +220,11 @@ __global__ __launch_bounds__(768, 1) void enc_x3_gemm(const float* __restrict__ 
     };
     for (int t = 0; t < Tr; t += 4) {
       step(t, rx[1]); step(t + 1, rx[2]); step(t + 2, rx[3]); step(t + 3, rx[0]);
+    }
+    if (!BWD && rng != nullptr) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o));
+      if (lane == 0) atomicMax(rng, __float_as_uint(xmax));  // non-negative floats order like their bit patterns
     }
   } else {
     // ---------------- consumers ----------------
@@ -273,6 +281,201 @@ __global__ __launch_bounds__(768, 1) void enc_x3_gemm(const float* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------
+// Backward GEMM on two fp16 terms per operand ("h2", x3_split.h): [dWmu; dWsig] = dpre^T * X with THREE fp16 matrix
+// products per fp32 product instead of six bf16 ones -- half the matrix energy on a chip that runs these kernels at
+// its power limit.  fp16 has no exponent range to spare, so both operands are scaled by powers of two
+// taken from their true maxima: max|X| was recorded by the forward kernel's producers while they streamed the same X
+// (rng[0]), max|dpre| by absmax_f32 below (rng[2]); the result is scaled back in the epilogue.  Same tile, roles and
+// barrier schedule as enc_x3_gemm<true>; LDS rows are 20 dwords (2 pieces x 8 + 4 pad: conflict-free 16-byte reads).
+// ------------------------------------------------------------------------------
+constexpr int kH2Row = 20;
+constexpr int kH2Sub = 128 * kH2Row + 32;
+constexpr int kH2Buf = 4 * kH2Sub;
+
+__global__ __launch_bounds__(256) void absmax_f32(const float* __restrict__ v, int64_t n, uint32_t* __restrict__ out) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(v[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// image of dpre^T in two fp16 terms: img[j][bt][s][piece][h][4 dwords], scaled by the power of two of rng[2]
+__global__ __launch_bounds__(256) void h2_split_cols(const float* __restrict__ P, int64_t B, int J, int rows_pad, int BT,
+                                                     uint32_t* __restrict__ img, const uint32_t* __restrict__ rng) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)rows_pad * BT * 4;
+  if (i >= total) return;
+  float sc, inv;
+  h2_scale_of(rng[2], &sc, &inv);
+  const int j = (int)(i % rows_pad);
+  const int64_t c = i / rows_pad;
+  const int64_t bt = c >> 2;
+  const int s = (int)(c >> 1) & 1, h = (int)c & 1;
+  const int64_t b = 8 * c;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (j < J && b + e < B) ? P[(b + e) * J + j] * sc : 0.f;
+  u32x4 Q[2];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const Split2 q = split2_pair(v[2 * e], v[2 * e + 1]);
+    Q[0][e] = q.h; Q[1][e] = q.l;
+  }
+  uint32_t* dst = img + (((int64_t)j * BT + bt) * 2 + s) * 16 + 4 * h;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(dst + 8 * p) = Q[p];
+}
+
+template <int NI, int NJ>
+__device__ __forceinline__ void h2_step(f32x16 (&acc)[NI][NJ], const u32x4 (&fa)[NI][2], const u32x4 (&fb)[NJ][2]) {
+  constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};  // lo*hi, hi*lo, hi*hi
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = mfma_f16(fa[i][PA[q]], fb[j][PB[q]], acc[i][j]);
+}
+
+__global__ __launch_bounds__(768, 1) void enc_h2_bwd_gemm(const float* __restrict__ X, int64_t B, int D, int J,
+                                                          const uint32_t* __restrict__ Pimg, int BT,
+                                                          float* __restrict__ out0, float* __restrict__ out1,
+                                                          const uint32_t* __restrict__ rng) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint32_t* lds = reinterpret_cast<uint32_t*>(smem_raw);  // [2][kH2Buf]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * 128;  // first column d
+  const int j0 = blockIdx.y * 128;
+  const int T = (int)(B / 32);
+  const int Tr = (T + 3) & ~3;
+  float sx, ix, sp, ip;
+  h2_scale_of(rng[0], &sx, &ix);
+  h2_scale_of(rng[2], &sp, &ip);
+
+  if (wave >= 8) {
+    // ---------------- producers of the dpre^T image ----------------
+    const int tid = threadIdx.x - 512;
+    const uint32_t* wptr[4];
+    int woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i, row = f >> 3, ch = f & 7;
+      const int s = ch >> 2, p = (ch >> 1) & 1, h = ch & 1;
+      wptr[i] = Pimg + (int64_t)(j0 + row) * BT * 32 + 4 * ch;
+      woff[i] = 2 * kH2Sub + s * kH2Sub + row * kH2Row + 8 * p + 4 * h;
+    }
+    u32x4 rw[kX3StagesW][4];
+    auto wload = [&](int t, u32x4 (&r)[4]) {
+      const int64_t kt = (t < T ? t : T - 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const u32x4*>(wptr[i] + kt * 32);
+    };
+    auto wstore = [&](int buf, const u32x4 (&w)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(lds + buf * kH2Buf + woff[i]) = w[i];
+    };
+    wload(0, rw[0]); wload(1, rw[1]); wload(2, rw[2]); wload(3, rw[3]);
+    wstore(0, rw[0]);
+    wload(4, rw[0]);
+    __syncthreads();  // P_{-1}
+    auto step = [&](int t, u32x4 (&w)[4]) {
+      wstore((t + 1) & 1, w);
+      wload(t + 5, w);
+      __syncthreads();  // P_t
+    };
+    for (int t = 0; t < Tr; t += 4) {
+      step(t, rw[1]); step(t + 1, rw[2]); step(t + 2, rw[3]); step(t + 3, rw[0]);
+    }
+  } else if (wave >= 4) {
+    // ---------------- X producers: columns d = m0 + 4c..4c+3, rows 4 rg..4 rg+3 of the macro tile ----------------
+    const int tid = threadIdx.x - 256;
+    const int c = tid & 31, rg = tid >> 5;
+    const float* xptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xptr[i] = X + (int64_t)(4 * rg + i) * D + m0 + 4 * c;
+    const int xoff = (rg >> 2) * kH2Sub + c * kH2Row + 4 * ((rg >> 1) & 1) + 2 * (rg & 1);
+    const int64_t xstep = 32 * (int64_t)D;
+    f32x4 rx[kX3StagesX][4];
+    auto xload = [&](int t, f32x4 (&r)[4]) {
+      const int64_t k0 = xstep * (t < T ? t : T - 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const f32x4*>(xptr[i] + k0);
+    };
+    auto xstore = [&](int buf, const f32x4 (&r)[4]) {
+      uint32_t* base = lds + buf * kH2Buf;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {  // column i of four consecutive rows (the reduction index) -> LDS row 32 i + c
+        const Split2 q0 = split2_pair(r[0][i] * sx, r[1][i] * sx);
+        const Split2 q1 = split2_pair(r[2][i] * sx, r[3][i] * sx);
+        *reinterpret_cast<u32x2*>(base + xoff + 32 * i * kH2Row) = u32x2{q0.h, q1.h};
+        *reinterpret_cast<u32x2*>(base + xoff + 32 * i * kH2Row + 8) = u32x2{q0.l, q1.l};
+      }
+    };
+    xload(0, rx[0]); xload(1, rx[1]); xload(2, rx[2]); xload(3, rx[3]);
+    xstore(0, rx[0]);
+    xload(4, rx[0]);
+    __syncthreads();  // P_{-1}
+    auto step = [&](int t, f32x4 (&r)[4]) {
+      xstore((t + 1) & 1, r);
+      xload(t + 5, r);
+      __syncthreads();  // P_t
+    };
+    for (int t = 0; t < Tr; t += 4) {
+      step(t, rx[1]); step(t + 1, rx[2]); step(t + 2, rx[3]); step(t + 3, rx[0]);
+    }
+  } else {
+    // ---------------- consumers ----------------
+    const int wm = wave >> 1, wn = wave & 1;
+    const uint32_t* a0 = lds + (wm * 64 + l31) * kH2Row + 4 * hh;
+    const uint32_t* b0 = lds + 2 * kH2Sub + (wn * 64 + l31) * kH2Row + 4 * hh;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
+    u32x4 fa[2][2][2], fb[2][2][2];  // [sub-step][tile][piece]
+    auto lread = [&](int buf, int s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          fa[s][i][p] = *reinterpret_cast<const u32x4*>(a0 + buf * kH2Buf + s * kH2Sub + 32 * i * kH2Row + 8 * p);
+          fb[s][i][p] = *reinterpret_cast<const u32x4*>(b0 + buf * kH2Buf + s * kH2Sub + 32 * i * kH2Row + 8 * p);
+        }
+    };
+    __syncthreads();  // P_{-1}
+    for (int t = 0; t < T; ++t) {
+      lread(t & 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t > 0) h2_step<2, 2>(acc, fa[1], fb[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      lread(t & 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      h2_step<2, 2>(acc, fa[0], fb[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();  // P_t
+    }
+    h2_step<2, 2>(acc, fa[1], fb[1]);
+    for (int t = T; t < Tr; ++t) __syncthreads();
+    const int Kh = J / 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = j0 + (wn * 2 + j) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int mrow = (wm * 2 + i) * 32 + OIVAE_ROW(r, hh);
+          const int64_t d = m0 + 4 * (mrow & 31) + (mrow >> 5);  // LDS row rho -> column of X
+          if (col < J) (col < Kh ? out0 + (int64_t)col * D : out1 + (int64_t)(col - Kh) * D)[d] = (acc[i][j][r] * ix) * ip;
+        }
+      }
+  }
+}
+
 // Split image of dpre^T: img[j][bt][s][piece][16 b] from dpre [B, J]; rows j >= J and b >= B are zero.
 // One thread per (j, 8 consecutive b); consecutive threads take consecutive j (coalesced reads).
 __global__ __launch_bounds__(256) void x3_split_cols(const float* __restrict__ P, int64_t B, int J, int rows_pad, int BT,
@@ -319,7 +522,7 @@ bool x3_encoder_bwd_applies(const oivae_shape_t& s, int64_t B) {
 int64_t x3_encoder_ws_bytes(const oivae_shape_t& s, int64_t B) {
   if (!x3_encoder_applies(s)) return 0;
   const int64_t kt = x3_ktiles(s.D), bt = x3_encoder_bwd_applies(s, B) ? (B + 31) / 32 : 0;
-  return (int64_t)x3_rows_pad(2 * s.K) * (kt > bt ? kt : bt) * 48 * 4;  // 3 x bf16 per element of the larger image
+  return (int64_t)x3_rows_pad(2 * s.K) * (kt > bt ? kt : bt) * 48 * 4 + 256;  // 3 x bf16 per element of the larger image + ranges
 }
 
 int x3_encoder_fwd_splits(const oivae_shape_t& s, int64_t B) {
@@ -329,6 +532,16 @@ int x3_encoder_fwd_splits(const oivae_shape_t& s, int64_t B) {
   while (splits < kMaxEncSplits && tiles * splits < 512 && ktiles / (splits * 2) >= 16) splits *= 2;
   return splits;
 }
+
+// Ranges for the fp16 backward kernel: the last 256 bytes of the image region.  [0] = max|X| (bits) recorded by the
+// forward kernel, [2] = max|dpre|.  The host remembers which forward call filled [0]: the backward call takes the fp16
+// kernel only for the same X, batch and workspace (entry points are called from one thread).
+static inline uint32_t* x3_ranges(const oivae_shape_t& s, int64_t B, uint32_t* img) {
+  return img + (x3_encoder_ws_bytes(s, B) - 256) / 4;
+}
+static struct { const float* X; int64_t B; uint32_t* img; } g_last_fwd = {nullptr, 0, nullptr};
+// test hook: OIVAE_ENC=bf16 keeps the three-term bf16 backward kernel
+static inline bool h2_enabled() { const char* e = getenv("OIVAE_ENC"); return !(e && e[0] == 'b'); }
 
 int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params, const float* X, int64_t B,
                           float* pre, uint32_t* wimg, int splits, hipStream_t st) {
@@ -344,8 +557,11 @@ int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int klen = ((KT + splits - 1) / splits) * 32;
   const dim3 grid((unsigned)((B + 127) / 128), (unsigned)(Jp / 128), (unsigned)splits);
-  hipLaunchKernelGGL(enc_x3_gemm<false>, grid, dim3(768), lds, st, X, B, s.D, J, wimg, KT, pre, (float*)nullptr, klen);
+  uint32_t* rng = x3_ranges(s, B, wimg);
+  OIVAE_HIP_CHECK(hipMemsetAsync(rng, 0, 256, st));
+  hipLaunchKernelGGL(enc_x3_gemm<false>, grid, dim3(768), lds, st, X, B, s.D, J, wimg, KT, pre, (float*)nullptr, klen, rng);
   OIVAE_LAUNCH_CHECK();
+  g_last_fwd = {X, B, wimg};
   return OIVAE_OK;
 }
 
@@ -356,6 +572,21 @@ int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, 
   const int J = 2 * s.K, Jp = x3_rows_pad(J);
   const int BT = (int)((B + 31) / 32);
   const int64_t chunks = (int64_t)Jp * BT * 4;
+  if (h2_enabled() && g_last_fwd.X == X && g_last_fwd.B == B && g_last_fwd.img == img) {
+    uint32_t* rng = x3_ranges(s, B, img);
+    OIVAE_HIP_CHECK(hipMemsetAsync(rng + 2, 0, 4, st));
+    hipLaunchKernelGGL(absmax_f32, dim3(1024), dim3(256), 0, st, dpre, B * (int64_t)J, rng + 2);
+    OIVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(h2_split_cols, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, dpre, B, J, Jp, BT, img, rng);
+    OIVAE_LAUNCH_CHECK();
+    const size_t lds = sizeof(uint32_t) * 2 * kH2Buf;
+    OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_h2_bwd_gemm),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const dim3 grid((unsigned)(s.D / 128), (unsigned)(Jp / 128), 1);
+    hipLaunchKernelGGL(enc_h2_bwd_gemm, grid, dim3(768), lds, st, X, B, s.D, J, img, BT, grads->enc_Wmu, grads->enc_Wsig, rng);
+    OIVAE_LAUNCH_CHECK();
+    return OIVAE_OK;
+  }
   hipLaunchKernelGGL(x3_split_cols, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, dpre, B, J, Jp, BT, img);
   OIVAE_LAUNCH_CHECK();
   const size_t lds = sizeof(uint32_t) * 2 * kX3Buf;
@@ -363,7 +594,7 @@ int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 grid((unsigned)(s.D / 128), (unsigned)(Jp / 128), 1);
   hipLaunchKernelGGL(enc_x3_gemm<true>, grid, dim3(768), lds, st, X, B, s.D, J, img, BT, grads->enc_Wmu,
-                     grads->enc_Wsig, 0);
+                     grads->enc_Wsig, 0, (uint32_t*)nullptr);
   OIVAE_LAUNCH_CHECK();
   return OIVAE_OK;
 }

@@ -59,4 +59,33 @@ __device__ __forceinline__ void x3mm(x3_f32x16& acc, const Frag3& A, const Frag3
   acc = mfma_bf16(A.p[0], B.p[0], acc);
 }
 
+// ---- two fp16 terms per operand ("h2"): x * scale = hi + lo with hi = fp16(x s), lo = fp16(x s - hi) (11 + 11
+// significand bits); a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulation.  As accurate
+// as the fp32 matrix instruction WHEN max|operand| * scale sits in [2^8, 2^15] (tools/probe/f16x2_accuracy.hip):
+// the caller owns the scale (a power of two, so scaling is exact).
+typedef _Float16 x3_h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 x3_h16x8 __attribute__((ext_vector_type(8)));
+typedef float x3_f32x2 __attribute__((ext_vector_type(2)));
+struct Split2 { uint32_t h, l; };
+__device__ __forceinline__ Split2 split2_pair(float a, float b) {   // a, b already scaled
+  Split2 r;
+  const x3_h16x2 h = __builtin_convertvector(x3_f32x2{a, b}, x3_h16x2);
+  const x3_f32x2 hf = __builtin_convertvector(h, x3_f32x2);
+  const x3_h16x2 l = __builtin_convertvector(x3_f32x2{a - hf[0], b - hf[1]}, x3_h16x2);
+  r.h = __builtin_bit_cast(uint32_t, h);
+  r.l = __builtin_bit_cast(uint32_t, l);
+  return r;
+}
+__device__ __forceinline__ x3_f32x16 mfma_f16(x3_u32x4 a, x3_u32x4 b, x3_f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x3_h16x8, a), __builtin_bit_cast(x3_h16x8, b), c, 0, 0, 0);
+}
+// power-of-two scale that brings a maximum with biased exponent E to [2^13, 2^14); 1 for zero, denormal, tiny (< 2^-113)
+// or non-finite maxima.  `inv` is its reciprocal.
+__device__ __forceinline__ void h2_scale_of(uint32_t absmax_bits, float* scale, float* inv) {
+  const uint32_t E = (absmax_bits >> 23) & 0xffu;
+  const bool ok = E >= 14u && E <= 254u;
+  *scale = ok ? __uint_as_float((267u - E) << 23) : 1.0f;
+  *inv = ok ? __uint_as_float((E - 13u) << 23) : 1.0f;
+}
+
 }  // namespace oivae
