@@ -53,7 +53,8 @@ __device__ __forceinline__ void x3_step(f32x16 (&acc)[NI][NJ], const u32x4 (&fa)
 // ------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void x3_split_rows(const float* __restrict__ W0, const float* __restrict__ W1,
                                                      int rows0, int rows, int Kd, int rows_pad, int KT,
-                                                     uint32_t* __restrict__ img) {
+                                                     uint32_t* __restrict__ img, const uint32_t* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;  // the fp16 forward kernel's result stands (h2_fwd_guard)
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)rows_pad * KT * 4;  // 8-wide chunks
   if (i >= total) return;
@@ -110,7 +111,8 @@ template <bool BWD>
 __global__ __launch_bounds__(768, 1) void enc_x3_gemm(const float* __restrict__ X, int64_t B, int D, int J,
                                                       const uint32_t* __restrict__ Wimg, int KT,
                                                       float* __restrict__ out0, float* __restrict__ out1, int klen,
-                                                      uint32_t* __restrict__ rng) {
+                                                      uint32_t* __restrict__ rng, const uint32_t* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;  // uniform, before any barrier: the fp16 forward kernel's result stands
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint32_t* lds = reinterpret_cast<uint32_t*>(smem_raw);  // [2][kX3Buf]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -476,6 +478,200 @@ __global__ __launch_bounds__(768, 1) void enc_h2_bwd_gemm(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------
+// Forward GEMM on two fp16 terms per operand.  The weights' scale comes from a reduction over them (rng[1]).  X is seen
+// here for the first time in the step, so the kernel runs with the power of two of the PREVIOUS forward call's max|X|
+// (rng[4], kept across calls) while its producers record this call's maximum (rng[0]); h2_fwd_guard accepts the result
+// only if both give the same scale -- otherwise it raises rng[3] and a second launch of the same kernel, which returns
+// at once while the flag is down, repeats the product with the right scale.  Either way the result is the one the
+// scale of X's own maximum gives: a function of the inputs alone, bit-reproducible, whatever came before.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void h2_split_rows(const float* __restrict__ W0, const float* __restrict__ W1,
+                                                     int rows0, int rows, int Kd, int rows_pad, int KT,
+                                                     uint32_t* __restrict__ img, const uint32_t* __restrict__ rng) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)rows_pad * KT * 4;
+  if (i >= total) return;
+  float sc, inv;
+  h2_scale_of(rng[1], &sc, &inv);
+  const int row = (int)(i / (KT * 4)), c = (int)(i % (KT * 4));
+  const int kt = c >> 2, s = (c >> 1) & 1, h = c & 1;
+  const int k = 8 * c;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  if (row < rows) {
+    const float* src = (row < rows0 ? W0 + (int64_t)row * Kd : W1 + (int64_t)(row - rows0) * Kd);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (k + e < Kd) v[e] = src[k + e] * sc;
+  }
+  u32x4 Q[2];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const Split2 q = split2_pair(v[2 * e], v[2 * e + 1]);
+    Q[0][e] = q.h; Q[1][e] = q.l;
+  }
+  uint32_t* dst = img + (((int64_t)row * KT + kt) * 2 + s) * 16 + 4 * h;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(dst + 8 * p) = Q[p];
+}
+
+__global__ void h2_fwd_guard(uint32_t* rng) {
+  float sp, ip, sc, ic;
+  h2_scale_of(rng[4], &sp, &ip);   // the scale the kernel used
+  h2_scale_of(rng[0], &sc, &ic);   // the scale of the maximum it saw
+  rng[3] = (sp == sc) ? 0u : 1u;   // accepted only if they are the same: the result is then a function of X and W alone
+  rng[4] = rng[0];
+}
+
+__global__ __launch_bounds__(768, 1) void enc_h2_fwd_gemm(const float* __restrict__ X, int64_t B, int D, int J,
+                                                          const uint32_t* __restrict__ Wimg, int KT,
+                                                          float* __restrict__ out0, int klen, uint32_t* __restrict__ rng,
+                                                          const uint32_t* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;  // second launch: only if the guard rejected the first one's scale
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint32_t* lds = reinterpret_cast<uint32_t*>(smem_raw);  // [2][kH2Buf]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * 128;
+  const int j0 = blockIdx.y * 128;
+  const int kbeg = blockIdx.z * klen;
+  const int kend = (kbeg + klen < D) ? kbeg + klen : D;
+  const int T = (kend - kbeg) / 32;
+  const int Tr = (T + 3) & ~3;
+  float* pre = out0 + (int64_t)blockIdx.z * B * J;
+  float sx, ix, sw, iw;
+  h2_scale_of(rng[4], &sx, &ix);
+  h2_scale_of(rng[1], &sw, &iw);
+
+  if (wave >= 8) {
+    // ---------------- producers of the weight image ----------------
+    const int tid = threadIdx.x - 512;
+    const uint32_t* wptr[4];
+    int woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i, row = f >> 3, ch = f & 7;
+      const int s = ch >> 2, p = (ch >> 1) & 1, h = ch & 1;
+      wptr[i] = Wimg + ((int64_t)(j0 + row) * KT + (kbeg >> 5)) * 32 + 4 * ch;
+      woff[i] = 2 * kH2Sub + s * kH2Sub + row * kH2Row + 8 * p + 4 * h;
+    }
+    u32x4 rw[kX3StagesW][4];
+    auto wload = [&](int t, u32x4 (&r)[4]) {
+      const int64_t kt = (t < T ? t : T - 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const u32x4*>(wptr[i] + kt * 32);
+    };
+    auto wstore = [&](int buf, const u32x4 (&w)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(lds + buf * kH2Buf + woff[i]) = w[i];
+    };
+    wload(0, rw[0]); wload(1, rw[1]); wload(2, rw[2]); wload(3, rw[3]);
+    wstore(0, rw[0]);
+    wload(4, rw[0]);
+    __syncthreads();  // P_{-1}
+    auto step = [&](int t, u32x4 (&w)[4]) {
+      wstore((t + 1) & 1, w);
+      wload(t + 5, w);
+      __syncthreads();  // P_t
+    };
+    for (int t = 0; t < Tr; t += 4) {
+      step(t, rw[1]); step(t + 1, rw[2]); step(t + 2, rw[3]); step(t + 3, rw[0]);
+    }
+  } else if (wave >= 4) {
+    // ---------------- X producers ----------------
+    const int tid = threadIdx.x - 256;
+    const int xr0 = tid >> 3, xc = tid & 7;
+    const int xr = (xr0 & ~3) | ((xr0 & 1) << 1) | ((xr0 >> 1) & 1);  // rows of a 16-lane group two apart (see enc_x3_gemm)
+    const float* xptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t row = m0 + xr + 32 * i;
+      xptr[i] = X + (row < B ? row : B - 1) * (int64_t)D + kbeg + 4 * xc;
+    }
+    const int xoff = (xc >> 2) * kH2Sub + xr * kH2Row + 4 * ((xc >> 1) & 1) + 2 * (xc & 1);
+    f32x4 rx[kX3StagesX][4];
+    auto xload = [&](int t, f32x4 (&r)[4]) {
+      const int64_t k0 = 32 * (int64_t)(t < T ? t : T - 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const f32x4*>(xptr[i] + k0);
+    };
+    float xmax = 0.f;
+    auto xstore = [&](int buf, const f32x4 (&r)[4]) {
+      uint32_t* base = lds + buf * kH2Buf;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xmax = fmaxf(fmaxf(xmax, fmaxf(fabsf(r[i][0]), fabsf(r[i][1]))), fmaxf(fabsf(r[i][2]), fabsf(r[i][3])));
+        const Split2 q0 = split2_pair(r[i][0] * sx, r[i][1] * sx);
+        const Split2 q1 = split2_pair(r[i][2] * sx, r[i][3] * sx);
+        *reinterpret_cast<u32x2*>(base + xoff + 32 * i * kH2Row) = u32x2{q0.h, q1.h};
+        *reinterpret_cast<u32x2*>(base + xoff + 32 * i * kH2Row + 8) = u32x2{q0.l, q1.l};
+      }
+    };
+    xload(0, rx[0]); xload(1, rx[1]); xload(2, rx[2]); xload(3, rx[3]);
+    xstore(0, rx[0]);
+    xload(4, rx[0]);
+    __syncthreads();  // P_{-1}
+    auto step = [&](int t, f32x4 (&r)[4]) {
+      xstore((t + 1) & 1, r);
+      xload(t + 5, r);
+      __syncthreads();  // P_t
+    };
+    for (int t = 0; t < Tr; t += 4) {
+      step(t, rx[1]); step(t + 1, rx[2]); step(t + 2, rx[3]); step(t + 3, rx[0]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o));
+    if (lane == 0) atomicMax(rng, __float_as_uint(xmax));
+  } else {
+    // ---------------- consumers ----------------
+    const int wm = wave >> 1, wn = wave & 1;
+    const uint32_t* a0 = lds + (wm * 64 + l31) * kH2Row + 4 * hh;
+    const uint32_t* b0 = lds + 2 * kH2Sub + (wn * 64 + l31) * kH2Row + 4 * hh;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
+    u32x4 fa[2][2][2], fb[2][2][2];
+    auto lread = [&](int buf, int s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          fa[s][i][p] = *reinterpret_cast<const u32x4*>(a0 + buf * kH2Buf + s * kH2Sub + 32 * i * kH2Row + 8 * p);
+          fb[s][i][p] = *reinterpret_cast<const u32x4*>(b0 + buf * kH2Buf + s * kH2Sub + 32 * i * kH2Row + 8 * p);
+        }
+    };
+    __syncthreads();  // P_{-1}
+    for (int t = 0; t < T; ++t) {
+      lread(t & 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t > 0) h2_step<2, 2>(acc, fa[1], fb[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      lread(t & 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      h2_step<2, 2>(acc, fa[0], fb[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();  // P_t
+    }
+    h2_step<2, 2>(acc, fa[1], fb[1]);
+    for (int t = T; t < Tr; ++t) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = j0 + (wn * 2 + j) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + (wm * 2 + i) * 32 + OIVAE_ROW(r, hh);
+          if (row < B && col < J) pre[row * J + col] = (acc[i][j][r] * ix) * iw;
+        }
+      }
+  }
+}
+
 // Split image of dpre^T: img[j][bt][s][piece][16 b] from dpre [B, J]; rows j >= J and b >= B are zero.
 // One thread per (j, 8 consecutive b); consecutive threads take consecutive j (coalesced reads).
 __global__ __launch_bounds__(256) void x3_split_cols(const float* __restrict__ P, int64_t B, int J, int rows_pad, int BT,
@@ -549,18 +745,39 @@ int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params,
     return fail(OIVAE_E_ARG, "x3 encoder: X and the workspace must be 16-byte aligned");
   const int J = 2 * s.K, Jp = x3_rows_pad(J), KT = x3_ktiles(s.D);
   const int64_t chunks = (int64_t)Jp * KT * 4;
-  hipLaunchKernelGGL(x3_split_rows, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, params->enc_Wmu,
-                     params->enc_Wsig, s.K, J, s.D, Jp, KT, wimg);
-  OIVAE_LAUNCH_CHECK();
   const size_t lds = sizeof(uint32_t) * 2 * kX3Buf;
   OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_x3_gemm<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int klen = ((KT + splits - 1) / splits) * 32;
   const dim3 grid((unsigned)((B + 127) / 128), (unsigned)(Jp / 128), (unsigned)splits);
   uint32_t* rng = x3_ranges(s, B, wimg);
-  OIVAE_HIP_CHECK(hipMemsetAsync(rng, 0, 256, st));
-  hipLaunchKernelGGL(enc_x3_gemm<false>, grid, dim3(768), lds, st, X, B, s.D, J, wimg, KT, pre, (float*)nullptr, klen, rng);
-  OIVAE_LAUNCH_CHECK();
+  OIVAE_HIP_CHECK(hipMemsetAsync(rng, 0, 16, st));   // [0] max|X| of this call, [1] max|W|, [2] max|dpre|, [3] redo flag
+  if (h2_enabled()) {
+    hipLaunchKernelGGL(absmax_f32, dim3(512), dim3(256), 0, st, params->enc_Wmu, (int64_t)s.K * s.D, rng + 1);
+    hipLaunchKernelGGL(absmax_f32, dim3(512), dim3(256), 0, st, params->enc_Wsig, (int64_t)s.K * s.D, rng + 1);
+    OIVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(h2_split_rows, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, params->enc_Wmu,
+                       params->enc_Wsig, s.K, J, s.D, Jp, KT, wimg, rng);
+    OIVAE_LAUNCH_CHECK();
+    const size_t lds2 = sizeof(uint32_t) * 2 * kH2Buf;
+    OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_h2_fwd_gemm),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    hipLaunchKernelGGL(enc_h2_fwd_gemm, grid, dim3(768), lds2, st, X, B, s.D, J, wimg, KT, pre, klen, rng,
+                       (const uint32_t*)nullptr);
+    OIVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(h2_fwd_guard, dim3(1), dim3(1), 0, st, rng);
+    OIVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(enc_h2_fwd_gemm, grid, dim3(768), lds2, st, X, B, s.D, J, wimg, KT, pre, klen, rng,
+                       (const uint32_t*)(rng + 3));
+    OIVAE_LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(x3_split_rows, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, params->enc_Wmu,
+                       params->enc_Wsig, s.K, J, s.D, Jp, KT, wimg, (const uint32_t*)nullptr);
+    OIVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(enc_x3_gemm<false>, grid, dim3(768), lds, st, X, B, s.D, J, wimg, KT, pre, (float*)nullptr, klen,
+                       rng, (const uint32_t*)nullptr);
+    OIVAE_LAUNCH_CHECK();
+  }
   g_last_fwd = {X, B, wimg};
   return OIVAE_OK;
 }
@@ -594,7 +811,7 @@ int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 grid((unsigned)(s.D / 128), (unsigned)(Jp / 128), 1);
   hipLaunchKernelGGL(enc_x3_gemm<true>, grid, dim3(768), lds, st, X, B, s.D, J, img, BT, grads->enc_Wmu,
-                     grads->enc_Wsig, 0, (uint32_t*)nullptr);
+                     grads->enc_Wsig, 0, (uint32_t*)nullptr, (const uint32_t*)nullptr);
   OIVAE_LAUNCH_CHECK();
   return OIVAE_OK;
 }
