@@ -1,5 +1,6 @@
-"""GPU tests of the encoder GEMMs that carry every fp32 operand as three bf16 terms and issue six bf16 matrix
-products per fp32 product (oi_vae_amd/csrc/x3_encoder.hip).  The claim under test: the result is fp32-grade --
+"""GPU tests of the encoder GEMMs that carry every fp32 operand in 16-bit terms (oi_vae_amd/csrc/x3_encoder.hip): the
+default, two scaled fp16 terms and three fp16 matrix products per fp32 product ("x3" below, the library's default
+mode), and three bf16 terms with six products (OIVAE_ENC=bf16).  The claim under test: the result is fp32-grade --
 against a float64 product of the same fp32 inputs its error is no larger than that of the fp32 matrix
 instructions (OIVAE_ENC=fp32 selects those; the library reads the variable on every call).
 Tolerances: 5e-6 of the result's largest magnitude absolute, and at most 1.5x the fp32 path's own error + 2e-7."""
@@ -14,8 +15,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _mode(name):
-  if name == "fp32":
-    os.environ["OIVAE_ENC"] = "fp32"
+  if name in ("fp32", "bf16"):
+    os.environ["OIVAE_ENC"] = name
   else:
     os.environ.pop("OIVAE_ENC", None)
 
@@ -36,10 +37,11 @@ def _engine(D, K, seed):
   return eng, g
 
 
-def _encoder_fwd(eng, X, eps):
+def _encoder_fwd(eng, X, eps, fresh_ws=True):
   from oi_vae_amd import _lib
   B, K = X.shape[0], eng.spec.K
-  eng._ws_key = None
+  if fresh_ws:
+    eng._ws_key = None
   ws = eng._workspace(B, eps.shape[0])
   mu, sig, ea = (torch.empty(B, K, device="cuda") for _ in range(3))
   z = torch.empty(eps.shape[0] * B, K, device="cuda")
@@ -52,8 +54,10 @@ def _encoder_fwd(eng, X, eps):
 
 
 def _check(err, scale):
-  assert err["x3"] <= 5e-6 * scale, err
-  assert err["x3"] <= 1.5 * err["fp32"] + 2e-7 * scale, err
+  for m in err:
+    if m != "fp32":
+      assert err[m] <= 5e-6 * scale, err
+      assert err[m] <= 1.5 * err["fp32"] + 2e-7 * scale, err
 
 
 @pytest.mark.parametrize("B,D", [(4096, 8192), (200, 1536), (1000, 4096)])
@@ -64,15 +68,17 @@ def test_forward_product_is_fp32_grade(B, D):
   eps = torch.zeros(1, B, 64, device="cuda")
   want = (X.double() @ eng.p["enc_Wmu"].double().t() + eng.p["enc_bmu"].double()).cpu()
   err = {}
-  for mode in ("fp32", "x3"):
+  for mode in ("fp32", "bf16", "x3"):
     _mode(mode)
     err[mode] = float((_encoder_fwd(eng, X, eps) - want).abs().max())
   _check(err, float(want.abs().max()))
 
 
 def test_forward_wide_dynamic_range_and_signs():
-  """bf16 keeps fp32's exponent range, so the split needs no scaling: operands from 1e-30 to 1e+12 with both
-  signs, exact zeros and denormals in one product."""
+  """Operands from 1e-30 to 1e+12 with both signs, exact zeros and denormals in one product.  bf16 keeps fp32's
+  exponent range and needs no scaling; the fp16 kernel scales by the power of two of max|X| and keeps every element
+  to an absolute error of 2^-39 of that maximum, which is what a product judged at the scale of its largest terms
+  needs (every row here has terms near 1e+12)."""
   B, D = 512, 2048
   eng, g = _engine(D, 64, seed=5)
   mag = torch.rand(B, D, generator=g, device="cuda") * 42 - 30          # exponents -30 .. +12
@@ -82,7 +88,7 @@ def test_forward_wide_dynamic_range_and_signs():
   eps = torch.zeros(1, B, 64, device="cuda")
   want = (X.double() @ eng.p["enc_Wmu"].double().t() + eng.p["enc_bmu"].double()).cpu()
   err = {}
-  for mode in ("fp32", "x3"):
+  for mode in ("fp32", "bf16", "x3"):
     _mode(mode)
     got = _encoder_fwd(eng, X, eps)
     assert torch.isfinite(got).all()
@@ -212,3 +218,58 @@ def test_paired_decoder_tiny_batches(B, S):
     if n:
       ga, gb = a[0][o:o + n], b[0][o:o + n]
       assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-12, name
+
+
+def test_fp16_forward_depends_on_its_inputs_only():
+  """The fp16 forward kernel starts from the scale of the previous call's X (kept in the workspace) and repeats the
+  product when this call's maximum asks for another one: whatever was multiplied before -- larger, smaller, all-zero
+  inputs, a fresh workspace -- the result for a given X is bit-identical and fp32-grade."""
+  B, D = 640, 4096
+  eng, g = _engine(D, 64, seed=9)
+  X = torch.rand(B, D, generator=g, device="cuda")
+  eps = torch.zeros(1, B, 64, device="cuda")
+  want = (X.double() @ eng.p["enc_Wmu"].double().t() + eng.p["enc_bmu"].double()).cpu()
+  first = _encoder_fwd(eng, X, eps)                                    # fresh workspace: no usable history
+  assert float((first - want).abs().max()) <= 5e-6 * float(want.abs().max())
+  again = _encoder_fwd(eng, X, eps, fresh_ws=False)                    # history = the same X: first launch accepted
+  assert torch.equal(first, again)
+  for factor in (4096.0, 1.0 / 65536.0, 0.0, 3.0e-20, 7.0e15):
+    Y = X * factor
+    wantY = (Y.double() @ eng.p["enc_Wmu"].double().t() + eng.p["enc_bmu"].double()).cpu()
+    gotY = _encoder_fwd(eng, Y, eps, fresh_ws=False)
+    assert torch.isfinite(gotY).all()
+    assert float((gotY - wantY).abs().max()) <= 5e-6 * max(float(wantY.abs().max()), 1e-30), factor
+    back = _encoder_fwd(eng, X, eps, fresh_ws=False)                   # ... and back to X after each of them
+    assert torch.equal(first, back), factor
+
+
+def test_fp16_backward_weight_gradient_is_fp32_grade():
+  """The fp16 backward kernel needs max|X| from the forward call of the same step (same X, batch and workspace);
+  without that call the library takes the bf16 kernel (test_backward_weight_gradient_is_fp32_grade).  Here the forward
+  call comes first: dWmu = dz^T X against float64 for the fp16, bf16 and fp32-instruction kernels, gradients of
+  very different magnitudes included."""
+  from oi_vae_amd import _lib
+  B, D, K = 4096, 8192, 64
+  eng, g = _engine(D, K, seed=17)
+  X = torch.rand(B, D, generator=g, device="cuda")
+  zeros, ones = torch.zeros(B, K, device="cuda"), torch.ones(B, K, device="cuda")
+  eps = torch.zeros(1, B, K, device="cuda")
+  pm, ps = torch.zeros(1, K, device="cuda"), torch.ones(1, K, device="cuda")
+  for gscale in (1.0, 1e-9, 3e4):
+    dzT = torch.randn(K, B, generator=g, device="cuda") * (gscale / B)
+    want = (dzT.double() @ X.double()).cpu()
+    err = {}
+    for mode in ("fp32", "bf16", "x3"):
+      _mode(mode)
+      _encoder_fwd(eng, X, eps)                                           # records max|X| for the backward call
+      ws = eng._workspace(B, 1)
+      eng.flat_grads.fill_(float("nan"))
+      _lib.check(eng.lib.oivae_encoder_bwd_f32(ctypes.byref(eng._shape), ctypes.byref(eng._gt), X.data_ptr(), B, 1,
+                 eps.data_ptr(), 1.0, pm.data_ptr(), ps.data_ptr(), 1, zeros.data_ptr(), ones.data_ptr(), ones.data_ptr(),
+                 dzT.data_ptr(), ws.data_ptr(), eng._ws_bytes, eng._stream()), "encoder_bwd")
+      torch.cuda.synchronize()
+      got = eng.g["enc_Wmu"].double().cpu()
+      assert torch.isfinite(got).all()
+      err[mode] = float((got - want).abs().max())
+      assert float(eng.g["enc_Wsig"].abs().max()) == 0.0
+    _check(err, float(want.abs().max()))
