@@ -244,10 +244,12 @@ def main():
                            "tools/probe/mfma_power.hip; the kernel is bound by the vector issue port, DESIGN.md 3.0)"},
       "step_model_tflops": (decoder_flops_per_row() + encoder_flops_per_row()) * GLOBAL_BATCH / (ms * 1e-3) / 1e12 / world,
       "entry_ms": {k: sum(v) / len(v) for k, v in per_kernel.items()},
-      "arithmetic": "fp32 in, fp32 out, fp32 accumulation everywhere.  Decoder and encoder GEMMs: each fp32 operand "
-                    "carried exactly as three bf16 terms, six v_mfma_f32_32x32x16_bf16 products per fp32 product "
-                    "(x3_split.h); error against float64 no larger than the fp32 matrix instructions' "
-                    "(tests/test_gpu_x3.py); OIVAE_ENC=fp32 OIVAE_DEC=v4 select the fp32 matrix instructions",
+      "arithmetic": "fp32 in, fp32 out, fp32 accumulation everywhere.  Decoder: each fp32 operand carried exactly as "
+                    "three bf16 terms, six v_mfma_f32_32x32x16_bf16 products per fp32 product.  Encoder GEMMs: two "
+                    "fp16 terms per operand after an exact power-of-two scaling by the operand's maximum, three "
+                    "v_mfma_f32_32x32x16_f16 products per fp32 product (x3_split.h).  Error against float64 no larger "
+                    "than the fp32 matrix instructions' (tests/test_gpu_x3.py); OIVAE_ENC=bf16 selects the bf16 "
+                    "encoder kernels, OIVAE_ENC=fp32 OIVAE_DEC=v4 the fp32 matrix instructions",
     }
     if world == 1:
       out["prox_roofline"] = prox_roofline(device)
