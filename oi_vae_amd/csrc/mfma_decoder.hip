@@ -54,6 +54,7 @@ struct MfmaDecArgs {
   float sig_off;
   double* ll_part;
   const uint32_t* zimg;  // dec_x3_64: split image of z (x3_split_z), else unused
+  const uint32_t* rng;   // dec_x3_64h: [0] max|X| (fp16 forward encoder), [5] max|z|
 };
 
 __device__ __forceinline__ float fast_tanh(float x) {
@@ -928,11 +929,20 @@ constexpr int kX3DecLds = (4 * 6144 + 192 + 3 * 64 * 65) * 4;  // images | b1, b
 
 __device__ __forceinline__ int x3_slot_feature(int ks, int hh, int e) { return 16 * ks + 8 * (e >> 2) + 4 * hh + (e & 3); }
 
+__global__ __launch_bounds__(256) void dec_absmax_f32(const float* __restrict__ v, int64_t n, uint32_t* __restrict__ out) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(v[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
 // Split image of z for dec_x3_64, shared by all groups: per 32-row tile 24 fragments of 1 KB,
 //   [0..11]  (ks, term): transposed orientation, lane (row l31, half hh), slot e <-> latent x3_slot_feature(ks, hh, e)
 //   [12..23] (kb, q, term): plain orientation, lane (latent 32 kb + l31, half hh), slot e <-> row 16 q + 8 (e/4) + 4 hh + e%4
 // rows past N repeat row N-1 (the decoder zeroes their gradients).
-__global__ __launch_bounds__(256) void x3_split_z(const float* __restrict__ z, int64_t N, uint32_t* __restrict__ img) {
+__global__ __launch_bounds__(256) void x3_split_z(const float* __restrict__ z, int64_t N, uint32_t* __restrict__ img,
+                                                  const uint32_t* __restrict__ rng) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t tiles = (N + 31) / 32;
   if (i >= tiles * 512) return;
@@ -952,6 +962,14 @@ __global__ __launch_bounds__(256) void x3_split_z(const float* __restrict__ z, i
       n = n < N ? n : N - 1;
       v[e] = z[n * 64 + 32 * kb + l31];
     }
+  }
+  if (rng != nullptr && grp < 4) {   // dec_x3_64h: two fp16 terms of z * 2^e in fragments 2 grp, 2 grp + 1
+    float sz, iz;
+    h2_scale_of(rng[5], &sz, &iz);
+    const Frag2 f2 = split8_h2(v[0] * sz, v[1] * sz, v[2] * sz, v[3] * sz, v[4] * sz, v[5] * sz, v[6] * sz, v[7] * sz);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<x3_u32x4*>(img + ((tile * 24 + grp * 2 + p) * 64 + lane) * 4) = f2.p[p];
+    return;
   }
   const Frag3 f = split8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 #pragma unroll
@@ -1581,6 +1599,395 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
 }
 
 
+// ------------------------------------------------------------------------------------------------------------
+// dec_x3_64h: dec_x3_64p with the CHAIN wave on two fp16 terms per operand and three products (x3_split.h "h2"):
+// 96 instead of 192 matrix instructions per tile on the critical path, a 6- instead of 11-instruction split.  The
+// weight-gradient wave, the published fp32 tiles and the end of the kernel are unchanged (three bf16 terms).
+// fp16 has no exponent range to spare: every chain operand is scaled by a power of two taken from its maximum --
+// the weight images from reductions at set-up, z from a reduction before its image is built (rng[5]), t by 2^13 --
+// or from a bound of it: |mu - x| <= max_d(|b2| + sum_m |W2|) + max|X| (rng[0], recorded by the fp16 forward encoder),
+// |gmu| <= max c3 times that, |da1| <= max_m sum_d |W2| times that.  A bound may be loose by 2^13 before precision
+// suffers (the scaled maximum only has to stay above 2^0).  Needs the forward encoder call of the same X.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
+  constexpr int K = 64, H = 64, M = 64, DG = 64, LW = 65;
+  constexpr float kC = 2.885390081777927f;  // 2*log2(e): tanh(x) = 1 - 2/(exp2(kC x) + 1)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint32_t* img = reinterpret_cast<uint32_t*>(smem_raw);   // [4][2 rb][4 ks][3 terms][64 lanes][4 dwords]
+  float* sb1 = reinterpret_cast<float*>(img + 4 * 6144);   // kC * b1
+  float* sb2 = sb1 + 64;
+  float* sC3 = sb2 + 64;                                   // inv / sigma_d^2
+  float* scr = sC3 + 64;                                   // 3 x [64][65] fp32 staging
+  volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(scr + 3 * 64 * LW);  // [4 streams][published, consumed]
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int g = blockIdx.x, chunk = blockIdx.y, nchunks = gridDim.y;
+  const bool chainw = wave < 4;
+  const int sw = wave & 3;
+  constexpr float kSt = 8192.0f;   // t lies in (-1, 1)
+  float s0 = 1.f, s1 = 1.f, s2 = 1.f, sz = 1.f, sg = 1.f, sd = 1.f, inv1 = 1.f, inv2 = 1.f, inv3 = 1.f, inv4 = 1.f;
+  {
+    float* tW1 = scr;
+    float* tWs = scr + 64 * LW;
+    float* tW2 = scr + 2 * 64 * LW;
+    const float* Wsg = a.Ws + (int64_t)g * K * H;
+    const float* W1g = a.W1 + (int64_t)g * M * H;
+    const float* W2g = a.W2 + (int64_t)g * DG * M;
+    for (int i = tid; i < 4096; i += 512) {
+      const int o = (i >> 6) * LW + (i & 63);
+      tW1[o] = W1g[i];
+      tWs[o] = Wsg[i];
+      tW2[o] = W2g[i];
+    }
+    if (tid < 64) {
+      const float sg = expf(a.ls[(int64_t)g * DG + tid]) + a.sig_off;
+      sb1[tid] = kC * a.b1[(int64_t)g * M + tid];
+      sb2[tid] = a.b2[(int64_t)g * DG + tid];
+      sC3[tid] = (a.inv / sg) / sg;
+    }
+    if (tid < 16) flags[tid] = 0;
+    __syncthreads();
+    // A[m][k] = sum_h W1[m][h] Ws[k][h] on the fp32 matrix instruction, one 32 x 32 block per chain wave
+    f32x16 acc = (f32x16)(0.f);
+    const int mt = sw >> 1, kt = sw & 1;
+    if (chainw) {
+      const float* pa = tW1 + (32 * mt + l31) * LW + hh;
+      const float* pb = tWs + (32 * kt + l31) * LW + hh;
+#pragma unroll 8
+      for (int s2 = 0; s2 < 32; ++s2) acc = mf32(pa[2 * s2], pb[2 * s2], acc);
+    }
+    __syncthreads();
+    if (chainw) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tW1[(32 * mt + OIVAE_ROW(r, hh)) * LW + 32 * kt + l31] = acc[r];
+    }
+    __syncthreads();
+    const float* A = tW1;
+    // ---- ranges: every fp16 operand gets a power-of-two scale from its maximum or from a bound of it ----
+    uint32_t* red = const_cast<uint32_t*>(flags) + 9;   // [0] max|A| [1] max|W2| [2] max_d(|b2| + sum_m |W2|) [3] max_m sum_d |W2| [4] max c3
+    {
+      float mA = 0.f, mW = 0.f;
+      for (int i = tid; i < 4096; i += 512) {
+        const int o = (i >> 6) * LW + (i & 63);
+        mA = fmaxf(mA, fabsf(A[o]));
+        mW = fmaxf(mW, fabsf(tW2[o]));
+      }
+      atomicMax(red + 0, __float_as_uint(mA));
+      atomicMax(red + 1, __float_as_uint(mW));
+      if (tid < 64) {
+        float rs = fabsf(sb2[tid]);
+        for (int m = 0; m < 64; ++m) rs += fabsf(tW2[tid * LW + m]);
+        atomicMax(red + 2, __float_as_uint(rs));
+        atomicMax(red + 4, __float_as_uint(sC3[tid]));
+      } else if (tid < 128) {
+        float cs = 0.f;
+        for (int d = 0; d < 64; ++d) cs += fabsf(tW2[d * LW + (tid - 64)]);
+        atomicMax(red + 3, __float_as_uint(cs));
+      }
+    }
+    __syncthreads();
+    {
+      const float mA = __uint_as_float(red[0]), mW = __uint_as_float(red[1]);
+      const float rmax = __uint_as_float(red[2]) + __uint_as_float(a.rng[0]);
+      const float gmax = __uint_as_float(red[4]) * rmax, dmax = __uint_as_float(red[3]) * gmax;
+      float i0, i1, i2, iz, ig, id;
+      h2_scale_of(__float_as_uint(kC * mA), &s0, &i0);
+      h2_scale_of(__float_as_uint(mA), &s1, &i1);
+      h2_scale_of(__float_as_uint(mW), &s2, &i2);
+      h2_scale_of(a.rng[5], &sz, &iz);
+      h2_scale_of(__float_as_uint(gmax), &sg, &ig);
+      h2_scale_of(__float_as_uint(dmax), &sd, &id);
+      inv1 = i0 * iz; inv2 = i2 * (1.0f / kSt); inv3 = i2 * ig; inv4 = i1 * id;
+    }
+    __syncthreads();   // every thread has read the maxima before the biases change
+    if (tid < 64) {
+      sb1[tid] *= s0 * sz;    // accumulator initial values in the products' scaled units
+      sb2[tid] *= s2 * kSt;
+    }
+    {  // the four images in two fp16 terms: item = (row r, step ks, lane half h2) -> 8 slots -> two 16-byte terms
+      const int item = tid;
+      const int r = item >> 3, ks = (item >> 1) & 3, h2 = item & 1;
+      float v[4][8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = x3_slot_feature(ks, h2, e);
+        v[0][e] = (kC * s0) * A[r * LW + c];
+        v[1][e] = s1 * A[c * LW + r];
+        v[2][e] = s2 * tW2[r * LW + c];
+        v[3][e] = s2 * tW2[c * LW + r];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const Frag2 f = split8_h2(v[q][0], v[q][1], v[q][2], v[q][3], v[q][4], v[q][5], v[q][6], v[q][7]);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          *reinterpret_cast<x3_u32x4*>(img + q * 4096 + ((((r >> 5) * 4 + ks) * 2 + p) * 64 + h2 * 32 + (r & 31)) * 4) = f.p[p];
+      }
+    }
+    __syncthreads();
+  }
+  const uint32_t* imgl = img + lane * 4;
+  auto wfrag = [&](int which, int rb, int ks) {
+    Frag2 f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) f.p[p] = *reinterpret_cast<const x3_u32x4*>(imgl + which * 4096 + ((rb * 4 + ks) * 2 + p) * 256);
+    return f;
+  };
+  auto afrag2 = [&](const f32x16& v, int q, float sc) {
+    return split8_h2(v[8 * q] * sc, v[8 * q + 1] * sc, v[8 * q + 2] * sc, v[8 * q + 3] * sc, v[8 * q + 4] * sc,
+                     v[8 * q + 5] * sc, v[8 * q + 6] * sc, v[8 * q + 7] * sc);
+  };
+  auto afrag = [&](const f32x16& v, int q) {
+    return split8(v[8 * q], v[8 * q + 1], v[8 * q + 2], v[8 * q + 3], v[8 * q + 4], v[8 * q + 5], v[8 * q + 6], v[8 * q + 7]);
+  };
+  // One chained product, both 32-row output blocks, as eight pinned units (u = 4 rb + ks) of six MFMAs: the weight
+  // fragments of unit u+2 are requested and the operand of step u+1 is split inside unit u's region, so that LDS
+  // latency and the split's vector work sit under MFMAs already issued (left to itself the scheduler requests a
+  // fragment one MFMA before its use and waits for it).  `side(u)`: independent work to place in unit u.
+  auto chain_mm = [&](f32x16* acc, int which, Frag2* bf, auto&& make, auto&& side) {
+    Frag2 w[3];
+    w[0] = wfrag(which, 0, 0);
+    w[1] = wfrag(which, 0, 1);
+    bf[0] = make(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u + 2 < 8) w[(u + 2) % 3] = wfrag(which, (u + 2) >> 2, (u + 2) & 3);
+      if (u + 1 < 4) bf[u + 1] = make(u + 1);
+      side(u);
+      h2mm(acc[u >> 2], w[u % 3], bf[u & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto init_t = [&](f32x16& acc, const float* vec, int rb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(vec + 32 * rb + 8 * q + 4 * hh);
+      acc[4 * q] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
+    }
+  };
+  auto zfrag2_of = [&](int t, int f) {   // two-term fragments of z * sz (x3_split_z with ranges)
+    Frag2 r;
+    const uint32_t* zi = a.zimg + ((int64_t)t * 24 * 64 + lane) * 4;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) r.p[p] = *reinterpret_cast<const x3_u32x4*>(zi + (f * 2 + p) * 256);
+    return r;
+  };
+  auto zfrag_of = [&](int t, int f) {
+    Frag3 r;
+    const uint32_t* zi = a.zimg + ((int64_t)t * 24 * 64 + lane) * 4;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) r.p[p] = *reinterpret_cast<const x3_u32x4*>(zi + (f * 3 + p) * 256);
+    return r;
+  };
+  // the stream's fp32 tile [32 rows][68]: written 16 bytes at a time with lane = batch row, read with lane = feature
+  constexpr int LT = 68;
+  float* tr = scr + sw * (32 * LT);
+  float* trw = tr + l31 * LT + 4 * hh;
+  const float* trr = tr + (4 * hh) * LT + l31;
+  auto tr_write = [&](const f32x16& v, int rb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<f32x4*>(trw + 32 * rb + 8 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+  };
+  auto tr_read = [&](int cb) {
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = trr[(8 * (r >> 2) + (r & 3)) * LT + 32 * cb];
+    return v;
+  };
+  volatile uint32_t* f_pub = flags + 2 * sw;
+  volatile uint32_t* f_con = flags + 2 * sw + 1;
+
+  const int N32 = (int)a.N;
+  const int ntiles = (N32 + 31) / 32;
+  const bool one_sample = (a.N == a.B);
+  f32x16 dW2a[2][2], Pa[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { dW2a[i][j] = (f32x16)(0.f); Pa[i][j] = (f32x16)(0.f); }
+  float sg1[2] = {0.f, 0.f}, sg2[2] = {0.f, 0.f}, sd1[2] = {0.f, 0.f};
+
+  if (chainw) {
+    // =============================== chain wave ===============================
+    __builtin_amdgcn_s_setprio(3);   // the critical path of the pair: issue before the other wave of the SIMD
+    uint32_t pub = 0;
+    Frag2 zf[4];
+    if (chunk * 4 + sw < ntiles) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) zf[ks] = zfrag2_of(chunk * 4 + sw, ks);
+    }
+    for (int tile = chunk * 4 + sw; tile < ntiles; tile += 4 * nchunks) {
+      const int tnext = (tile + 4 * nchunks < ntiles) ? tile + 4 * nchunks : tile;
+      const int r0 = tile * 32;
+      const int nT = (r0 + l31 < N32) ? r0 + l31 : N32 - 1;
+      const float liveT = (r0 + l31 < N32) ? 1.0f : 0.0f;
+      const float* xT = a.X + (one_sample ? (int64_t)nT : (int64_t)nT % a.B) * (int64_t)a.D + (int64_t)g * DG + 4 * hh;
+      f32x4 xq[2][4];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xq[rb][q] = *reinterpret_cast<const f32x4*>(xT + 32 * rb + 8 * q);
+      // ---- kC (a1 + b1) in units of 1 / inv1 ----
+      f32x16 uT[2];
+      init_t(uT[0], sb1, 0);
+      init_t(uT[1], sb1, 1);
+      auto none = [&](int) {};
+      chain_mm(uT, 0, zf, [&](int ks) { return zf[ks]; }, none);
+      // ---- t = tanh: published first, split during the next product ----
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          uT[rb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(uT[rb][r] * inv1) + 1.0f);
+      lds_wait_ge(f_con, pub);
+      tr_write(uT[0], 0);
+      tr_write(uT[1], 1);
+      lds_post(f_pub, ++pub);
+      // ---- mu = W2 t + b2; gmu = (mu - x) inv / sigma^2; afterwards uT holds inv3 (1 - t^2) ----
+      Frag2 tf[4];
+      f32x16 gT[2];
+      init_t(gT[0], sb2, 0);
+      init_t(gT[1], sb2, 1);
+      auto gmu_quarter = [&](int rb, int q) {
+        const f32x4 c3 = *reinterpret_cast<const f32x4*>(sC3 + 32 * rb + 8 * q + 4 * hh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gT[rb][4 * q + i] = fmaf(gT[rb][4 * q + i], inv2, -xq[rb][q][i]) * (c3[i] * liveT);
+      };
+      chain_mm(gT, 2, tf,
+               [&](int ks) {
+                 const Frag2 f = afrag2(uT[ks >> 1], ks & 1, kSt);
+                 if (ks & 1) {
+#pragma unroll
+                   for (int r = 0; r < 16; ++r) uT[ks >> 1][r] = fmaf(-inv3 * uT[ks >> 1][r], uT[ks >> 1][r], inv3);
+                 }
+                 return f;
+               },
+               [&](int u) { if (u >= 4) gmu_quarter(0, u - 4); });
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gmu_quarter(1, q);
+      lds_wait_ge(f_con, pub);
+      tr_write(gT[0], 0);
+      tr_write(gT[1], 1);
+      lds_post(f_pub, ++pub);
+      // ---- dt = W2^T gmu; da1 = dt (1 - t^2) ----
+      Frag2 gf[4];
+      f32x16 dT[2];
+      dT[0] = (f32x16)(0.f);
+      dT[1] = (f32x16)(0.f);
+      chain_mm(dT, 3, gf, [&](int ks) { return afrag2(gT[ks >> 1], ks & 1, sg); },
+               [&](int u) {
+                 if (u >= 4) {
+#pragma unroll
+                   for (int r = 4 * (u - 4); r < 4 * (u - 4) + 4; ++r) dT[0][r] *= uT[0][r];
+                 }
+               });
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dT[1][r] *= uT[1][r];
+      lds_wait_ge(f_con, pub);
+      tr_write(dT[0], 0);
+      tr_write(dT[1], 1);
+      lds_post(f_pub, ++pub);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) zf[ks] = zfrag2_of(tnext, ks);   // the next tile's first operand, one product ahead
+      // ---- dz^T[k][n] += sum_m A[m][k] da1[n][m] ----
+      Frag2 df[4];
+      f32x16 dz[2];
+      dz[0] = (f32x16)(0.f);
+      dz[1] = (f32x16)(0.f);
+      float* dzp = a.dzT + (int64_t)(4 * hh) * a.N + nT;
+      const bool liveRow = r0 + l31 < N32;
+      chain_mm(dz, 1, df, [&](int ks) { return afrag2(dT[ks >> 1], ks & 1, sd); },
+               [&](int u) {
+                 if (u >= 4 && liveRow) {
+#pragma unroll
+                   for (int r = 4 * (u - 4); r < 4 * (u - 4) + 4; ++r)
+                     atomicAdd(dzp + (int64_t)(8 * (r >> 2) + (r & 3)) * a.N, dz[0][r] * inv4);
+                 }
+               });
+      if (liveRow) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(dzp + (int64_t)(32 + 8 * (r >> 2) + (r & 3)) * a.N, dz[1][r] * inv4);
+      }
+    }
+  } else {
+    // =============================== weight-gradient wave ===============================
+    uint32_t seen = 0;
+    for (int tile = chunk * 4 + sw; tile < ntiles; tile += 4 * nchunks) {
+      f32x16 rd[2];
+      Frag3 tNf[2][2];
+      // ---- t ----
+      lds_wait_ge(f_pub, seen + 1);
+      rd[0] = tr_read(0);
+      rd[1] = tr_read(1);
+      lds_post(f_con, ++seen);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) { tNf[mb][0] = afrag(rd[mb], 0); tNf[mb][1] = afrag(rd[mb], 1); }
+      // ---- gmu: column sums, dW2[d][m] += sum_n gmu[n][d] t[n][m] ----
+      lds_wait_ge(f_pub, seen + 1);
+      rd[0] = tr_read(0);
+      rd[1] = tr_read(1);
+      lds_post(f_con, ++seen);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1 += rd[i][r]; s2 = fmaf(rd[i][r], rd[i][r], s2); }
+        sg1[i] += s1;
+        sg2[i] += s2;
+        const Frag3 g0 = afrag(rd[i], 0), g1 = afrag(rd[i], 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          x3mm(dW2a[i][j], g0, tNf[j][0]);
+          x3mm(dW2a[i][j], g1, tNf[j][1]);
+        }
+      }
+      // ---- da1: column sums, P[m][k] += sum_n da1[n][m] z[n][k] (z's fragments requested before the wait) ----
+      Frag3 zn[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) zn[f] = zfrag_of(tile, 4 + f);
+      lds_wait_ge(f_pub, seen + 1);
+      rd[0] = tr_read(0);
+      rd[1] = tr_read(1);
+      lds_post(f_con, ++seen);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float sd = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sd += rd[i][r];
+        sd1[i] += sd;
+        const Frag3 d0 = afrag(rd[i], 0), d1 = afrag(rd[i], 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          x3mm(Pa[i][j], d0, zn[2 * j]);
+          x3mm(Pa[i][j], d1, zn[2 * j + 1]);
+        }
+      }
+    }
+  }
+  // per-column sums: the two lane halves of a column are added through LDS, lane L then holds column L
+  __syncthreads();
+  float* tmp = scr + 2 * 64 * LW + sw * 384;
+  if (!chainw) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      tmp[(0 * 2 + b) * 64 + hh * 32 + l31] = sg1[b];
+      tmp[(1 * 2 + b) * 64 + hh * 32 + l31] = sg2[b];
+      tmp[(2 * 2 + b) * 64 + hh * 32 + l31] = sd1[b];
+    }
+  }
+  __syncthreads();
+  const int cb = lane >> 5;
+  const float cs_gmu = tmp[(0 * 2 + cb) * 64 + l31] + tmp[(0 * 2 + cb) * 64 + 32 + l31];
+  const float cs_gmu2 = tmp[(1 * 2 + cb) * 64 + l31] + tmp[(1 * 2 + cb) * 64 + 32 + l31];
+  const float cs_da1 = tmp[(2 * 2 + cb) * 64 + l31] + tmp[(2 * 2 + cb) * 64 + 32 + l31];
+  dec64_finish(a, g, chunk, tid & 255, sw, lane, dW2a, Pa, cs_gmu, cs_gmu2, cs_da1, reinterpret_cast<float*>(img), scr,
+               scr + 64 * LW, !chainw);
+}
+
+
 bool mfma_decoder_applies(const oivae_shape_t& s) {
   if (getenv("OIVAE_FORCE_GENERIC")) return false;  // test hook: cross-check the two kernel families
   if (s.gen_type != OIVAE_GEN_MLP) return false;
@@ -1641,22 +2048,37 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   a.sig_off = gen_sig_off;
   a.ll_part = w.ll_part;
   a.zimg = nullptr;
+  a.rng = nullptr;
   int rc;
   // OIVAE_DEC=v1 (test hook) selects the layer-by-layer template kernel for the all-64 shape, which also serves
   // launches whose dz image exceeds the 32-bit byte offsets of dec_mfma64_v4's atomics (N*K*4 >= 2^32)
   const char* dec_env = getenv("OIVAE_DEC");
   // test hooks: OIVAE_DEC=v1 the layer-by-layer fp32 template kernel, OIVAE_DEC=v4 the fp32 composed-first-layer
-  // kernel, OIVAE_DEC=x3 the single-wave-per-SIMD split-bf16 kernel; default for the all-64 shape: dec_x3_64p
+  // kernel, OIVAE_DEC=x3 the single-wave-per-SIMD split-bf16 kernel, OIVAE_DEC=p the all-bf16 pair; default for the
+  // all-64 shape: dec_x3_64h (dec_x3_64p without a matching forward encoder call)
   const bool force_v1 = dec_env != nullptr && dec_env[0] == 'v' && dec_env[1] == '1';
-  const bool use_x3 = dec_env == nullptr || dec_env[0] == 'x' || dec_env[0] == 'p';
-  const bool use_pair = dec_env == nullptr || dec_env[0] == 'p';
+  const bool use_x3 = dec_env == nullptr || dec_env[0] == 'x' || dec_env[0] == 'p' || dec_env[0] == 'h';
+  const bool use_pair = dec_env == nullptr || dec_env[0] == 'p' || dec_env[0] == 'h';
+  uint32_t* rng = x3_forward_ranges(X, B);
+  // default: the chain wave on fp16 terms when the fp16 forward encoder call of this X left its ranges, else dec_x3_64p
+  const bool use_h = rng != nullptr && s.K == 64 && (dec_env == nullptr || dec_env[0] == 'h');
   if (s.K == 64 && use_x3) {
     if (!w.x3_z) return fail(OIVAE_E_WORKSPACE, "x3 decoder: no z image in the workspace");
     const int64_t zt = (N + 31) / 32;
-    hipLaunchKernelGGL(x3_split_z, dim3((unsigned)((zt * 512 + 255) / 256)), dim3(256), 0, st, z, N, w.x3_z);
+    if (use_h) {
+      OIVAE_HIP_CHECK(hipMemsetAsync(rng + 5, 0, 4, st));
+      hipLaunchKernelGGL(dec_absmax_f32, dim3(512), dim3(256), 0, st, z, N * 64, rng + 5);
+      OIVAE_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(x3_split_z, dim3((unsigned)((zt * 512 + 255) / 256)), dim3(256), 0, st, z, N, w.x3_z, use_h ? rng : (const uint32_t*)nullptr);
     OIVAE_LAUNCH_CHECK();
     a.zimg = w.x3_z;
-    if (use_pair) {
+    a.rng = rng;
+    if (use_h) {
+      OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_x3_64h),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kX3DecLdsP));
+      hipLaunchKernelGGL(dec_x3_64h, dim3((unsigned)s.G, (unsigned)chunks), dim3(512), (size_t)kX3DecLdsP, st, a);
+    } else if (use_pair) {
       OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_x3_64p),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kX3DecLdsP));
       hipLaunchKernelGGL(dec_x3_64p, dim3((unsigned)s.G, (unsigned)chunks), dim3(512), (size_t)kX3DecLdsP, st, a);

@@ -88,4 +88,20 @@ __device__ __forceinline__ void h2_scale_of(uint32_t absmax_bits, float* scale, 
   *inv = ok ? __uint_as_float((E - 13u) << 23) : 1.0f;
 }
 
+// one MFMA operand in its two fp16 terms (inputs already scaled)
+struct Frag2 { x3_u32x4 p[2]; };
+__device__ __forceinline__ Frag2 split8_h2(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+  const Split2 a = split2_pair(v0, v1), b = split2_pair(v2, v3), c = split2_pair(v4, v5), d = split2_pair(v6, v7);
+  Frag2 f;
+  f.p[0] = x3_u32x4{a.h, b.h, c.h, d.h};
+  f.p[1] = x3_u32x4{a.l, b.l, c.l, d.l};
+  return f;
+}
+// acc += A * B over 16 reduction slots: lo*hi + hi*lo + hi*hi
+__device__ __forceinline__ void h2mm(x3_f32x16& acc, const Frag2& A, const Frag2& B) {
+  acc = mfma_f16(A.p[1], B.p[0], acc);
+  acc = mfma_f16(A.p[0], B.p[1], acc);
+  acc = mfma_f16(A.p[0], B.p[0], acc);
+}
+
 }  // namespace oivae

@@ -52,7 +52,7 @@ def test_mfma_kernels_agree_with_generic_kernels(tmp_path):
   script = tmp_path / "cross.py"
   script.write_text(_CROSS % {"root": ROOT})
   res = {}
-  for mode in ("mfma", "generic", "layerwise", "fp32", "onewave"):
+  for mode in ("mfma", "generic", "layerwise", "fp32", "onewave", "pair", "bf16"):
     env = dict(os.environ)
     if mode == "generic":
       env["OIVAE_FORCE_GENERIC"] = "1"
@@ -63,11 +63,15 @@ def test_mfma_kernels_agree_with_generic_kernels(tmp_path):
       env["OIVAE_ENC"] = "fp32"
     if mode == "onewave":
       env["OIVAE_DEC"] = "x3"   # the split-bf16 decoder with one wave per SIMD instead of the role-split pair
+    if mode == "pair":
+      env["OIVAE_DEC"] = "p"    # the role-split pair with both waves on bf16 terms (default: chain wave on fp16 terms)
+    if mode == "bf16":
+      env["OIVAE_ENC"] = "bf16"  # bf16 encoder kernels; the decoder then has no ranges and takes the all-bf16 pair
     out = tmp_path / (mode + ".npz")
     subprocess.run([sys.executable, str(script), mode, str(out)], check=True, env=env, timeout=300)
     res[mode] = np.load(out)
   eng = _engine(24, 64, 64, 64, 64, seed=1)  # segment-wise comparison relative to each tensor's scale
-  for other in ("generic", "layerwise", "fp32", "onewave"):
+  for other in ("generic", "layerwise", "fp32", "onewave", "pair", "bf16"):
     a, b = res["mfma"], res[other]
     assert np.max(np.abs(a["sc"][:6] - b["sc"][:6]) / np.maximum(np.abs(b["sc"][:6]), 1)) < 1e-5, other
     assert np.array_equal(a["z"], b["z"]) or np.max(np.abs(a["z"] - b["z"])) < 1e-5
