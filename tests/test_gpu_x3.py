@@ -273,3 +273,72 @@ def test_fp16_backward_weight_gradient_is_fp32_grade():
       err[mode] = float((got - want).abs().max())
       assert float(eng.g["enc_Wsig"].abs().max()) == 0.0
     _check(err, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("case", ["plain", "mixed_sigma", "large_x", "small_latent", "big_weights"])
+def test_fp16_chain_decoder_step_against_float64(case):
+  """The whole step at the all-64 shape (fp16 encoder kernels, dec_x3_64h) against float64 autograd of the same loss
+  on the same fp32 inputs, beside the fp32-instruction kernels (OIVAE_ENC=fp32 OIVAE_DEC=v4) whose error sets the
+  bar.  The cases move the ranges the fp16 scales are derived from: per-dimension sigmas from 2e-3 to 3 (gmu's bound
+  is max c3 times a bound of mu - x), inputs of magnitude 300, latents of magnitude 1e-3, generator weights of
+  magnitude 4."""
+  from tests.test_gpu_scale import _engine as scale_engine
+  G, K, B, S = 6, 64, 150, 2
+  eng = scale_engine(G, 64, K, 64, 64, seed=31)
+  g = torch.Generator(device="cuda").manual_seed(77)
+  xs = 1.0
+  if case == "mixed_sigma":
+    eng.p["log_sigma"].copy_(torch.log(torch.pow(10.0, torch.rand(eng.p["log_sigma"].shape, generator=g, device="cuda") * 3.2 - 2.7)))
+  if case == "large_x":
+    xs = 300.0
+    for n in ("enc_Wmu", "enc_Wsig"):
+      eng.p[n].mul_(1.0 / 300.0)     # keep the pre-activations (and exp of them) in range
+  if case == "small_latent":
+    for n in ("enc_Wmu", "enc_bmu"):
+      eng.p[n].mul_(1e-3)
+    eng.p["enc_bsig"].fill_(float(np.log(1e-3)))
+  if case == "big_weights":
+    eng.p["gen_W2"].mul_(32.0)
+    eng.p["gen_W1"].mul_(4.0)
+  X = torch.rand(B, G * 64, generator=g, device="cuda") * xs
+  eps = torch.randn(S, B, K, generator=g, device="cuda")
+
+  # float64 reference of loss = KL - loglik/(S B) - theta prior (lib/oivae.py:42-79), gradients by autograd
+  names = ("enc_Wmu", "enc_bmu", "enc_Wsig", "enc_bsig", "gen_W1", "gen_b1", "gen_W2", "gen_b2", "log_sigma", "Ws")
+  p64 = {n: eng.p[n].double().clone().requires_grad_(True) for n in names}
+  X64 = X.double()
+  mu_q = X64 @ p64["enc_Wmu"].view(K, -1).t() + p64["enc_bmu"]
+  sig_q = torch.exp(X64 @ p64["enc_Wsig"].view(K, -1).t() + p64["enc_bsig"]) * 0.7 + 1e-3
+  z = (mu_q[None] + sig_q[None] * eps.double()).reshape(S * B, K)
+  kl = (-0.5 + (sig_q ** 2 + mu_q ** 2) / 2 - torch.log(sig_q)).sum() / B
+  h = torch.einsum("nk,gkh->gnh", z, p64["Ws"].view(G, K, 64))
+  a1 = torch.einsum("gnh,gmh->gnm", h, p64["gen_W1"].view(G, 64, 64)) + p64["gen_b1"].view(G, 1, 64)
+  mu = torch.einsum("gnm,gdm->gnd", torch.tanh(a1), p64["gen_W2"].view(G, 64, 64)) + p64["gen_b2"].view(G, 1, 64)
+  sig = torch.exp(p64["log_sigma"].view(G, 1, 64)) + 1e-3
+  x = X64.repeat(S, 1).view(S * B, G, 64).permute(1, 0, 2)
+  ll = (-0.5 * np.log(2 * np.pi) - torch.log(sig) - 0.5 * ((x - mu) / sig) ** 2).sum() / S / B
+  theta = sum((-0.5 * np.log(2 * np.pi) - 0.5 * p64[n] ** 2).sum() for n in ("gen_W1", "gen_b1", "gen_W2", "gen_b2"))
+  (kl - ll - theta).backward()
+
+  err = {}
+  for mode in ("fp32", "default"):
+    if mode == "fp32":
+      os.environ["OIVAE_ENC"], os.environ["OIVAE_DEC"] = "fp32", "v4"
+    else:
+      os.environ.pop("OIVAE_ENC", None)
+      os.environ.pop("OIVAE_DEC", None)
+    eng._ws_key = None
+    eng.forward_backward(X, eps, 0.7)
+    torch.cuda.synchronize()
+    e = {}
+    for n in names:
+      want = p64[n].grad.reshape(-1).cpu()
+      got = eng.g[n].double().reshape(-1).cpu()
+      assert torch.isfinite(got).all(), (mode, n)
+      e[n] = float((got - want).abs().max() / want.abs().max())
+    err[mode] = e
+  os.environ.pop("OIVAE_ENC", None)
+  os.environ.pop("OIVAE_DEC", None)
+  for n in names:
+    assert err["default"][n] <= 2e-5, (case, n, err)
+    assert err["default"][n] <= 2.0 * err["fp32"][n] + 1e-6, (case, n, err)
