@@ -57,9 +57,10 @@ def decoder_executed_flops(rows):
 
 
 def decoder_bf16_flops(rows):
-  """bf16 matrix flops dec_x3_64p issues in the row loop: each of the six fp32 products becomes six bf16
-  products of the split operands: 288 v_mfma_f32_32x32x16_bf16 per 32-row tile and group."""
-  return (rows + 31) // 32 * G * 288 * (2 * 32 * 32 * 16)
+  """16-bit matrix flops dec_x3_64h issues in the row loop: the four chained fp32 products as three fp16 products each
+  (96 v_mfma_f32_32x32x16_f16 per 32-row tile and group), the two weight-gradient products as six bf16 products each
+  (96 v_mfma_f32_32x32x16_bf16): 192 instructions of 2*32*32*16 flops."""
+  return (rows + 31) // 32 * G * 192 * (2 * 32 * 32 * 16)
 
 
 def encoder_flops_per_row():
@@ -223,7 +224,7 @@ def main():
       "config": {"workload": "synthetic scale-up: G=1024 groups x 64 dims, K=64, H=M=64 two-layer generators, "
                              "global batch 65536, S=1", "global_batch": GLOBAL_BATCH,
                  "parallelism": "dp%d" % world, "rows_per_gpu": rows},
-      "roofline": {"bound": "mfma", "kernel": "dec_x3_64p (grouped decoder fwd+bwd)",
+      "roofline": {"bound": "mfma", "kernel": "dec_x3_64h (grouped decoder fwd+bwd)",
                    "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic() if world == 1 else None,
                    "avg_launch_ms": dec_avg, "flops_per_launch": dec_flops,
@@ -238,16 +239,17 @@ def main():
                    "note": "achieved/peak/frac: the reference algorithm's fp32 flops (9 products per group, SURVEY 8d) "
                            "against the fp32 matrix peak, as in earlier rounds -- above 1 because the kernel composes "
                            "Ws[g] with the generator's first Linear (6 products, executed_*) and issues each fp32 "
-                           "product as six bf16 matrix products of exactly split operands (bf16_*: the matrix "
+                           "product as three fp16 or six bf16 matrix products of split operands (bf16_*: the 16-bit matrix "
                            "instructions actually issued against the dense bf16 peak, bf16_sustained_peak: what the "
                            "power-limited chip reaches on that instruction alone with random operands, "
                            "tools/probe/mfma_power.hip; the kernel is bound by the vector issue port, DESIGN.md 3.0)"},
       "step_model_tflops": (decoder_flops_per_row() + encoder_flops_per_row()) * GLOBAL_BATCH / (ms * 1e-3) / 1e12 / world,
       "entry_ms": {k: sum(v) / len(v) for k, v in per_kernel.items()},
-      "arithmetic": "fp32 in, fp32 out, fp32 accumulation everywhere.  Decoder: each fp32 operand carried exactly as "
-                    "three bf16 terms, six v_mfma_f32_32x32x16_bf16 products per fp32 product.  Encoder GEMMs: two "
-                    "fp16 terms per operand after an exact power-of-two scaling by the operand's maximum, three "
-                    "v_mfma_f32_32x32x16_f16 products per fp32 product (x3_split.h).  Error against float64 no larger "
+      "arithmetic": "fp32 in, fp32 out, fp32 accumulation everywhere.  Encoder GEMMs and the decoder's four chained "
+                    "products: two fp16 terms per operand after an exact power-of-two scaling by the operand's "
+                    "maximum (or a bound of it), three v_mfma_f32_32x32x16_f16 products per fp32 product; the "
+                    "decoder's two weight-gradient products: three bf16 terms, six v_mfma_f32_32x32x16_bf16 products "
+                    "(x3_split.h).  Error against float64 no larger "
                     "than the fp32 matrix instructions' (tests/test_gpu_x3.py); OIVAE_ENC=bf16 selects the bf16 "
                     "encoder kernels, OIVAE_ENC=fp32 OIVAE_DEC=v4 the fp32 matrix instructions",
     }
