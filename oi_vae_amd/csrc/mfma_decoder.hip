@@ -963,7 +963,7 @@ __global__ __launch_bounds__(256) void x3_split_z(const float* __restrict__ z, i
       v[e] = z[n * 64 + 32 * kb + l31];
     }
   }
-  if (rng != nullptr && grp < 4) {   // dec_x3_64h: two fp16 terms of z * 2^e in fragments 2 grp, 2 grp + 1
+  if (rng != nullptr) {   // dec_x3_64h: two fp16 terms of z * 2^e in fragments 2 grp, 2 grp + 1 (both orientations)
     float sz, iz;
     h2_scale_of(rng[5], &sz, &iz);
     const Frag2 f2 = split8_h2(v[0] * sz, v[1] * sz, v[2] * sz, v[3] * sz, v[4] * sz, v[5] * sz, v[6] * sz, v[7] * sz);
@@ -1601,8 +1601,9 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
 
 // ------------------------------------------------------------------------------------------------------------
 // dec_x3_64h: dec_x3_64p with the CHAIN wave on two fp16 terms per operand and three products (x3_split.h "h2"):
-// 96 instead of 192 matrix instructions per tile on the critical path, a 6- instead of 11-instruction split.  The
-// weight-gradient wave, the published fp32 tiles and the end of the kernel are unchanged (three bf16 terms).
+// 96 instead of 192 matrix instructions per tile on the critical path, a 6- instead of 11-instruction split; the
+// weight-gradient wave likewise (48 instead of 96), its accumulators hold sums in scaled units and are scaled back
+// once before the end of the kernel, which is unchanged.
 // fp16 has no exponent range to spare: every chain operand is scaled by a power of two taken from its maximum --
 // the weight images from reductions at set-up, z from a reduction before its image is built (rng[5]), t by 2^13 --
 // or from a bound of it: |mu - x| <= max_d(|b2| + sum_m |W2|) + max|X| (rng[0], recorded by the fp16 forward encoder),
@@ -1627,6 +1628,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
   const int sw = wave & 3;
   constexpr float kSt = 8192.0f;   // t lies in (-1, 1)
   float s0 = 1.f, s1 = 1.f, s2 = 1.f, sz = 1.f, sg = 1.f, sd = 1.f, inv1 = 1.f, inv2 = 1.f, inv3 = 1.f, inv4 = 1.f;
+  float invW = 1.f, invP = 1.f;   // the weight-gradient accumulators' units: 1 / (sg 2^13) and 1 / (sd sz)
   {
     float* tW1 = scr;
     float* tWs = scr + 64 * LW;
@@ -1699,6 +1701,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
       h2_scale_of(__float_as_uint(gmax), &sg, &ig);
       h2_scale_of(__float_as_uint(dmax), &sd, &id);
       inv1 = i0 * iz; inv2 = i2 * (1.0f / kSt); inv3 = i2 * ig; inv4 = i1 * id;
+      invW = ig * (1.0f / kSt); invP = id * iz;
     }
     __syncthreads();   // every thread has read the maxima before the biases change
     if (tid < 64) {
@@ -1917,14 +1920,14 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
     uint32_t seen = 0;
     for (int tile = chunk * 4 + sw; tile < ntiles; tile += 4 * nchunks) {
       f32x16 rd[2];
-      Frag3 tNf[2][2];
+      Frag2 tNf[2][2];
       // ---- t ----
       lds_wait_ge(f_pub, seen + 1);
       rd[0] = tr_read(0);
       rd[1] = tr_read(1);
       lds_post(f_con, ++seen);
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) { tNf[mb][0] = afrag(rd[mb], 0); tNf[mb][1] = afrag(rd[mb], 1); }
+      for (int mb = 0; mb < 2; ++mb) { tNf[mb][0] = afrag2(rd[mb], 0, kSt); tNf[mb][1] = afrag2(rd[mb], 1, kSt); }
       // ---- gmu: column sums, dW2[d][m] += sum_n gmu[n][d] t[n][m] ----
       lds_wait_ge(f_pub, seen + 1);
       rd[0] = tr_read(0);
@@ -1937,35 +1940,41 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
         for (int r = 0; r < 16; ++r) { s1 += rd[i][r]; s2 = fmaf(rd[i][r], rd[i][r], s2); }
         sg1[i] += s1;
         sg2[i] += s2;
-        const Frag3 g0 = afrag(rd[i], 0), g1 = afrag(rd[i], 1);
+        const Frag2 g0 = afrag2(rd[i], 0, sg), g1 = afrag2(rd[i], 1, sg);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          x3mm(dW2a[i][j], g0, tNf[j][0]);
-          x3mm(dW2a[i][j], g1, tNf[j][1]);
+          h2mm(dW2a[i][j], g0, tNf[j][0]);
+          h2mm(dW2a[i][j], g1, tNf[j][1]);
         }
       }
       // ---- da1: column sums, P[m][k] += sum_n da1[n][m] z[n][k] (z's fragments requested before the wait) ----
-      Frag3 zn[4];
+      Frag2 zn[4];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) zn[f] = zfrag_of(tile, 4 + f);
+      for (int f = 0; f < 4; ++f) zn[f] = zfrag2_of(tile, 4 + f);
       lds_wait_ge(f_pub, seen + 1);
       rd[0] = tr_read(0);
       rd[1] = tr_read(1);
       lds_post(f_con, ++seen);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        float sd = 0.f;
+        float csum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sd += rd[i][r];
-        sd1[i] += sd;
-        const Frag3 d0 = afrag(rd[i], 0), d1 = afrag(rd[i], 1);
+        for (int r = 0; r < 16; ++r) csum += rd[i][r];
+        sd1[i] += csum;
+        const Frag2 d0 = afrag2(rd[i], 0, sd), d1 = afrag2(rd[i], 1, sd);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          x3mm(Pa[i][j], d0, zn[2 * j]);
-          x3mm(Pa[i][j], d1, zn[2 * j + 1]);
+          h2mm(Pa[i][j], d0, zn[2 * j]);
+          h2mm(Pa[i][j], d1, zn[2 * j + 1]);
         }
       }
     }
+  }
+  if (!chainw) {   // the accumulated weight gradients back into true units
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { dW2a[i][j] *= invW; Pa[i][j] *= invP; }
   }
   // per-column sums: the two lane halves of a column are added through LDS, lane L then holds column L
   __syncthreads();
