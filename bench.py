@@ -57,10 +57,10 @@ def decoder_executed_flops(rows):
 
 
 def decoder_bf16_flops(rows):
-  """16-bit matrix flops dec_x3_64h issues in the row loop: the four chained fp32 products as three fp16 products each
-  (96 v_mfma_f32_32x32x16_f16 per 32-row tile and group), the two weight-gradient products as six bf16 products each
-  (96 v_mfma_f32_32x32x16_bf16): 192 instructions of 2*32*32*16 flops."""
-  return (rows + 31) // 32 * G * 192 * (2 * 32 * 32 * 16)
+  """16-bit matrix flops dec_x3_64h issues in the row loop: each of the six fp32 products (2 x 2 blocks of 32 x 32,
+  four reduction steps of 16) as three fp16 products: 144 v_mfma_f32_32x32x16_f16 of 2*32*32*16 flops per 32-row
+  tile and group."""
+  return (rows + 31) // 32 * G * 144 * (2 * 32 * 32 * 16)
 
 
 def encoder_flops_per_row():
@@ -239,17 +239,16 @@ def main():
                    "note": "achieved/peak/frac: the reference algorithm's fp32 flops (9 products per group, SURVEY 8d) "
                            "against the fp32 matrix peak, as in earlier rounds -- above 1 because the kernel composes "
                            "Ws[g] with the generator's first Linear (6 products, executed_*) and issues each fp32 "
-                           "product as three fp16 or six bf16 matrix products of split operands (bf16_*: the 16-bit matrix "
+                           "product as three fp16 matrix products of split, scaled operands (bf16_*: the 16-bit matrix "
                            "instructions actually issued against the dense bf16 peak, bf16_sustained_peak: what the "
                            "power-limited chip reaches on that instruction alone with random operands, "
                            "tools/probe/mfma_power.hip; the kernel is bound by the vector issue port, DESIGN.md 3.0)"},
       "step_model_tflops": (decoder_flops_per_row() + encoder_flops_per_row()) * GLOBAL_BATCH / (ms * 1e-3) / 1e12 / world,
       "entry_ms": {k: sum(v) / len(v) for k, v in per_kernel.items()},
-      "arithmetic": "fp32 in, fp32 out, fp32 accumulation everywhere.  Encoder GEMMs and the decoder's four chained "
-                    "products: two fp16 terms per operand after an exact power-of-two scaling by the operand's "
-                    "maximum (or a bound of it), three v_mfma_f32_32x32x16_f16 products per fp32 product; the "
-                    "decoder's two weight-gradient products: three bf16 terms, six v_mfma_f32_32x32x16_bf16 products "
-                    "(x3_split.h).  Error against float64 no larger "
+      "arithmetic": "fp32 in, fp32 out, fp32 accumulation everywhere.  Encoder GEMMs and decoder products: two fp16 "
+                    "terms per operand after an exact power-of-two scaling by the operand's maximum (or a bound of "
+                    "it), three v_mfma_f32_32x32x16_f16 products per fp32 product (x3_split.h; the all-bf16 kernels, "
+                    "three terms and six products, serve calls without a matching forward encoder call).  Error against float64 no larger "
                     "than the fp32 matrix instructions' (tests/test_gpu_x3.py); OIVAE_ENC=bf16 selects the bf16 "
                     "encoder kernels, OIVAE_ENC=fp32 OIVAE_DEC=v4 the fp32 matrix instructions",
     }
