@@ -83,7 +83,13 @@ int oivae_init(int device);               /* idempotent; uploads the rsqrt14 tab
 const char* oivae_last_error(void);
 const char* oivae_version(void);
 
-/* Bytes of workspace the step entry points need for these shapes and N rows. */
+/* Bytes of workspace the step entry points need for these shapes and N rows.
+ * The three step entry points below are one step's sequence: encoder forward, decoder, encoder backward, on the same
+ * X, B and workspace, from one host thread.  At the shapes served by the matrix-core kernels the forward call leaves
+ * max|X| in the workspace (and keeps it for the next step's forward call); the decoder and backward calls use it to
+ * scale their fp16 operands when they follow a forward call of the same X and B, and take the scaling-free bf16
+ * kernels otherwise (INTEGRATION.md "Arithmetic and switches").  Results are the same to fp32
+ * accuracy either way; passing the same workspace every step saves the forward kernel a second pass. */
 int64_t oivae_workspace_bytes(const oivae_shape_t* shape, int64_t B, int32_t S);
 
 /* ---- proximal step ------------------------------------------------------
