@@ -101,7 +101,7 @@ int mfma_encoder_fwd_splits(const oivae_shape_t& s, int64_t B);  // mfma_encoder
 // x3_encoder.hip: fp32 GEMMs as six bf16 matrix products
 bool x3_encoder_applies(const oivae_shape_t& s);
 int64_t x3_encoder_ws_bytes(const oivae_shape_t& s, int64_t B);
-uint32_t* x3_forward_ranges(const float* X, int64_t B);  // ranges recorded by the fp16 forward encoder call, or nullptr
+uint32_t* x3_forward_ranges(const float* X, int64_t B, const uint32_t* img);  // ranges recorded by the fp16 forward encoder call, or nullptr
 int x3_encoder_fwd_splits(const oivae_shape_t& s, int64_t B);
 bool x3_encoder_bwd_applies(const oivae_shape_t& s, int64_t B);
 int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X, const float* dpre,

@@ -2068,7 +2068,7 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   const bool force_v1 = dec_env != nullptr && dec_env[0] == 'v' && dec_env[1] == '1';
   const bool use_x3 = dec_env == nullptr || dec_env[0] == 'x' || dec_env[0] == 'p' || dec_env[0] == 'h';
   const bool use_pair = dec_env == nullptr || dec_env[0] == 'p' || dec_env[0] == 'h';
-  uint32_t* rng = x3_forward_ranges(X, B);
+  uint32_t* rng = x3_forward_ranges(X, B, w.x3_img);
   // default: the chain wave on fp16 terms when the fp16 forward encoder call of this X left its ranges, else dec_x3_64p
   const bool use_h = rng != nullptr && s.K == 64 && (dec_env == nullptr || dec_env[0] == 'h');
   if (s.K == 64 && use_x3) {

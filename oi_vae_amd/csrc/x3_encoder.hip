@@ -738,9 +738,9 @@ static inline uint32_t* x3_ranges(const oivae_shape_t& s, int64_t B, uint32_t* i
 // test hook: OIVAE_ENC=bf16 keeps the three-term bf16 backward kernel
 static inline bool h2_enabled() { const char* e = getenv("OIVAE_ENC"); return !(e && e[0] == 'b'); }
 static struct { const float* X; int64_t B; uint32_t* img; uint32_t* rng; } g_last_fwd = {nullptr, 0, nullptr, nullptr};
-// for the decoder: the ranges recorded by the forward call of this X and batch, or nullptr
-uint32_t* x3_forward_ranges(const float* X, int64_t B) {
-  return (h2_enabled() && g_last_fwd.X == X && g_last_fwd.B == B) ? g_last_fwd.rng : nullptr;
+// for the decoder: the ranges recorded by the forward call of this X, batch and workspace (its image region), or nullptr
+uint32_t* x3_forward_ranges(const float* X, int64_t B, const uint32_t* img) {
+  return (h2_enabled() && g_last_fwd.X == X && g_last_fwd.B == B && g_last_fwd.img == img) ? g_last_fwd.rng : nullptr;
 }
 
 int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params, const float* X, int64_t B,
