@@ -931,10 +931,24 @@ __device__ __forceinline__ int x3_slot_feature(int ks, int hh, int e) { return 1
 
 __global__ __launch_bounds__(256) void dec_absmax_f32(const float* __restrict__ v, int64_t n, uint32_t* __restrict__ out) {
   float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(v[i]));
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  if ((reinterpret_cast<uintptr_t>(v) & 15) == 0) {   // 16 bytes per lane, scalar tail
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int64_t n4 = n >> 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      const f4 q = reinterpret_cast<const f4*>(v)[i];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(q[0]), fabsf(q[1]))), fmaxf(fabsf(q[2]), fabsf(q[3])));
+    }
+    for (int64_t i = 4 * n4 + tid; i < n; i += nth) m = fmaxf(m, fabsf(v[i]));
+  } else {
+    for (int64_t i = tid; i < n; i += nth) m = fmaxf(m, fabsf(v[i]));
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+  __shared__ float part[4];   // one atomic per workgroup: thousands of atomics on one address take 14 ns each
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
 }
 
 // Split image of z for dec_x3_64, shared by all groups: per 32-row tile 24 fragments of 1 KB,
@@ -2076,7 +2090,7 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
     const int64_t zt = (N + 31) / 32;
     if (use_h) {
       OIVAE_HIP_CHECK(hipMemsetAsync(rng + 5, 0, 4, st));
-      hipLaunchKernelGGL(dec_absmax_f32, dim3(512), dim3(256), 0, st, z, N * 64, rng + 5);
+      hipLaunchKernelGGL(dec_absmax_f32, dim3(256), dim3(256), 0, st, z, N * 64, rng + 5);
       OIVAE_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(x3_split_z, dim3((unsigned)((zt * 512 + 255) / 256)), dim3(256), 0, st, z, N, w.x3_z, use_h ? rng : (const uint32_t*)nullptr);

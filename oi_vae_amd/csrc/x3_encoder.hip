@@ -297,10 +297,24 @@ constexpr int kH2Buf = 4 * kH2Sub;
 
 __global__ __launch_bounds__(256) void absmax_f32(const float* __restrict__ v, int64_t n, uint32_t* __restrict__ out) {
   float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(v[i]));
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  if ((reinterpret_cast<uintptr_t>(v) & 15) == 0) {   // 16 bytes per lane, scalar tail
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int64_t n4 = n >> 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      const f4 q = reinterpret_cast<const f4*>(v)[i];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(q[0]), fabsf(q[1]))), fmaxf(fabsf(q[2]), fabsf(q[3])));
+    }
+    for (int64_t i = 4 * n4 + tid; i < n; i += nth) m = fmaxf(m, fabsf(v[i]));
+  } else {
+    for (int64_t i = tid; i < n; i += nth) m = fmaxf(m, fabsf(v[i]));
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+  __shared__ float part[4];   // one atomic per workgroup: thousands of atomics on one address take 14 ns each
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
 }
 
 // image of dpre^T in two fp16 terms: img[j][bt][s][piece][h][4 dwords], scaled by the power of two of rng[2]
@@ -757,8 +771,8 @@ int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params,
   uint32_t* rng = x3_ranges(s, B, wimg);
   OIVAE_HIP_CHECK(hipMemsetAsync(rng, 0, 16, st));   // [0] max|X| of this call, [1] max|W|, [2] max|dpre|, [3] redo flag
   if (h2_enabled()) {
-    hipLaunchKernelGGL(absmax_f32, dim3(512), dim3(256), 0, st, params->enc_Wmu, (int64_t)s.K * s.D, rng + 1);
-    hipLaunchKernelGGL(absmax_f32, dim3(512), dim3(256), 0, st, params->enc_Wsig, (int64_t)s.K * s.D, rng + 1);
+    hipLaunchKernelGGL(absmax_f32, dim3(256), dim3(256), 0, st, params->enc_Wmu, (int64_t)s.K * s.D, rng + 1);
+    hipLaunchKernelGGL(absmax_f32, dim3(256), dim3(256), 0, st, params->enc_Wsig, (int64_t)s.K * s.D, rng + 1);
     OIVAE_LAUNCH_CHECK();
     hipLaunchKernelGGL(h2_split_rows, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, params->enc_Wmu,
                        params->enc_Wsig, s.K, J, s.D, Jp, KT, wimg, rng);
@@ -796,7 +810,7 @@ int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, 
   if (h2_enabled() && g_last_fwd.X == X && g_last_fwd.B == B && g_last_fwd.img == img) {
     uint32_t* rng = x3_ranges(s, B, img);
     OIVAE_HIP_CHECK(hipMemsetAsync(rng + 2, 0, 4, st));
-    hipLaunchKernelGGL(absmax_f32, dim3(1024), dim3(256), 0, st, dpre, B * (int64_t)J, rng + 2);
+    hipLaunchKernelGGL(absmax_f32, dim3(256), dim3(256), 0, st, dpre, B * (int64_t)J, rng + 2);
     OIVAE_LAUNCH_CHECK();
     hipLaunchKernelGGL(h2_split_cols, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, dpre, B, J, Jp, BT, img, rng);
     OIVAE_LAUNCH_CHECK();
