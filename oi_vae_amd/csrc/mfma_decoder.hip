@@ -1642,7 +1642,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
   const int sw = wave & 3;
   constexpr float kSt = 8192.0f;   // t lies in (-1, 1)
   float s0 = 1.f, s1 = 1.f, s2 = 1.f, sz = 1.f, sg = 1.f, sd = 1.f, inv1 = 1.f, inv2 = 1.f, inv3 = 1.f, inv4 = 1.f;
-  float invW = 1.f, invP = 1.f;   // the weight-gradient accumulators' units: 1 / (sg 2^13) and 1 / (sd sz)
+  float invW = 1.f, invP = 1.f, invG = 1.f, invD = 1.f, omtC = 1.f;   // 1/sg, 1/sd, inv3 sd   // the weight-gradient accumulators' units: 1 / (sg 2^13) and 1 / (sd sz)
   {
     float* tW1 = scr;
     float* tWs = scr + 64 * LW;
@@ -1716,11 +1716,13 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
       h2_scale_of(__float_as_uint(dmax), &sd, &id);
       inv1 = i0 * iz; inv2 = i2 * (1.0f / kSt); inv3 = i2 * ig; inv4 = i1 * id;
       invW = ig * (1.0f / kSt); invP = id * iz;
+      invG = ig; invD = id; omtC = inv3 * sd;
     }
     __syncthreads();   // every thread has read the maxima before the biases change
     if (tid < 64) {
       sb1[tid] *= s0 * sz;    // accumulator initial values in the products' scaled units
       sb2[tid] *= s2 * kSt;
+      sC3[tid] *= sg;         // gmu is produced in its operand's scaled units
     }
     {  // the four images in two fp16 terms: item = (row r, step ks, lane half h2) -> 8 slots -> two 16-byte terms
       const int item = tid;
@@ -1750,6 +1752,9 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) f.p[p] = *reinterpret_cast<const x3_u32x4*>(imgl + which * 4096 + ((rb * 4 + ks) * 2 + p) * 256);
     return f;
+  };
+  auto afrag2n = [&](const f32x16& v, int q) {   // values already in scaled units
+    return split8_h2(v[8 * q], v[8 * q + 1], v[8 * q + 2], v[8 * q + 3], v[8 * q + 4], v[8 * q + 5], v[8 * q + 6], v[8 * q + 7]);
   };
   auto afrag2 = [&](const f32x16& v, int q, float sc) {
     return split8_h2(v[8 * q] * sc, v[8 * q + 1] * sc, v[8 * q + 2] * sc, v[8 * q + 3] * sc, v[8 * q + 4] * sc,
@@ -1858,7 +1863,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          uT[rb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(uT[rb][r] * inv1) + 1.0f);
+          uT[rb][r] = fmaf(-2.0f * kSt, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(uT[rb][r] * inv1) + 1.0f), kSt);   // 2^13 t
       lds_wait_ge(f_con, pub);
       tr_write(uT[0], 0);
       tr_write(uT[1], 1);
@@ -1875,10 +1880,10 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
       };
       chain_mm(gT, 2, tf,
                [&](int ks) {
-                 const Frag2 f = afrag2(uT[ks >> 1], ks & 1, kSt);
+                 const Frag2 f = afrag2n(uT[ks >> 1], ks & 1);
                  if (ks & 1) {
 #pragma unroll
-                   for (int r = 0; r < 16; ++r) uT[ks >> 1][r] = fmaf(-inv3 * uT[ks >> 1][r], uT[ks >> 1][r], inv3);
+                   for (int r = 0; r < 16; ++r) uT[ks >> 1][r] = fmaf(-(omtC / (kSt * kSt)) * uT[ks >> 1][r], uT[ks >> 1][r], omtC);
                  }
                  return f;
                },
@@ -1894,7 +1899,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
       f32x16 dT[2];
       dT[0] = (f32x16)(0.f);
       dT[1] = (f32x16)(0.f);
-      chain_mm(dT, 3, gf, [&](int ks) { return afrag2(gT[ks >> 1], ks & 1, sg); },
+      chain_mm(dT, 3, gf, [&](int ks) { return afrag2n(gT[ks >> 1], ks & 1); },
                [&](int u) {
                  if (u >= 4) {
 #pragma unroll
@@ -1916,7 +1921,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
       dz[1] = (f32x16)(0.f);
       float* dzp = a.dzT + (int64_t)(4 * hh) * a.N + nT;
       const bool liveRow = r0 + l31 < N32;
-      chain_mm(dz, 1, df, [&](int ks) { return afrag2(dT[ks >> 1], ks & 1, sd); },
+      chain_mm(dz, 1, df, [&](int ks) { return afrag2n(dT[ks >> 1], ks & 1); },
                [&](int u) {
                  if (u >= 4 && liveRow) {
 #pragma unroll
@@ -1941,7 +1946,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
       rd[1] = tr_read(1);
       lds_post(f_con, ++seen);
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) { tNf[mb][0] = afrag2(rd[mb], 0, kSt); tNf[mb][1] = afrag2(rd[mb], 1, kSt); }
+      for (int mb = 0; mb < 2; ++mb) { tNf[mb][0] = afrag2n(rd[mb], 0); tNf[mb][1] = afrag2n(rd[mb], 1); }
       // ---- gmu: column sums, dW2[d][m] += sum_n gmu[n][d] t[n][m] ----
       lds_wait_ge(f_pub, seen + 1);
       rd[0] = tr_read(0);
@@ -1954,7 +1959,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
         for (int r = 0; r < 16; ++r) { s1 += rd[i][r]; s2 = fmaf(rd[i][r], rd[i][r], s2); }
         sg1[i] += s1;
         sg2[i] += s2;
-        const Frag2 g0 = afrag2(rd[i], 0, sg), g1 = afrag2(rd[i], 1, sg);
+        const Frag2 g0 = afrag2n(rd[i], 0), g1 = afrag2n(rd[i], 1);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           h2mm(dW2a[i][j], g0, tNf[j][0]);
@@ -1975,7 +1980,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) csum += rd[i][r];
         sd1[i] += csum;
-        const Frag2 d0 = afrag2(rd[i], 0, sd), d1 = afrag2(rd[i], 1, sd);
+        const Frag2 d0 = afrag2n(rd[i], 0), d1 = afrag2n(rd[i], 1);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           h2mm(Pa[i][j], d0, zn[2 * j]);
@@ -1989,6 +1994,8 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) { dW2a[i][j] *= invW; Pa[i][j] *= invP; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { sg1[i] *= invG; sg2[i] *= invG * invG; sd1[i] *= invD; }   // the tiles were in scaled units
   }
   // per-column sums: the two lane halves of a column are added through LDS, lane L then holds column L
   __syncthreads();
