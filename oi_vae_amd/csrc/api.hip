@@ -83,10 +83,7 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
   w->kl_part = reinterpret_cast<double*>(take(sizeof(double) * kEncEpiBlocks));
   w->n_ll = plan.flat ? flat_decoder_blocks(s) : s.G * plan.chunks;
   w->ll_part = reinterpret_cast<double*>(take(sizeof(double) * kMaxPartials));
-  {
-    int64_t bb = (B + 63) / 64;  // at least 64 rows per block
-    w->n_bias = (int32_t)(bb > kBiasBlocks ? kBiasBlocks : bb);
-  }
+  w->n_bias = enc_bias_blocks(B);  // at least 64 rows per block
   w->bias_part = reinterpret_cast<double*>(take(sizeof(double) * kBiasBlocks * 2 * s.K));
   w->n_theta = 2048;  // 512 blocks per generator parameter array; every slot written each step
   w->theta_part = reinterpret_cast<double*>(take(sizeof(double) * 2048));
@@ -102,6 +99,7 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
   w->slab = reinterpret_cast<float*>(take(plan.chunks > 1 ? sizeof(float) * L.total * plan.chunks : 0));
   w->flat = reinterpret_cast<float*>(take(plan.flat ? sizeof(float) * flat_decoder_floats(s, N, nullptr) : 0));
   w->x3_img = reinterpret_cast<uint32_t*>(take(x3_encoder_ws_bytes(s, B)));
+  w->ranges = reinterpret_cast<uint32_t*>(take(256));
   w->x3_z = reinterpret_cast<uint32_t*>(take((plan.mfma && s.K == 64) ? ((N + 31) / 32) * 24 * 1024 : 0));
   w->total_bytes = off;
   if (p && bytes < off)
@@ -254,11 +252,14 @@ extern "C" int oivae_init(int device) {
   OIVAE_HIP_CHECK(hipGetDevice(&prev));
   OIVAE_HIP_CHECK(hipSetDevice(device));
   uint16_t* d = nullptr;
-  OIVAE_HIP_CHECK(hipMalloc(&d, nbytes));
-  OIVAE_HIP_CHECK(hipMemcpy(d, oivae_rsqrt14_blob, nbytes, hipMemcpyHostToDevice));
-  g_tab[device] = d;
-  OIVAE_HIP_CHECK(hipSetDevice(prev));
-  return OIVAE_OK;
+  hipError_t e = hipMalloc(&d, nbytes);
+  if (e == hipSuccess) e = hipMemcpy(d, oivae_rsqrt14_blob, nbytes, hipMemcpyHostToDevice);
+  int rc = OIVAE_OK;
+  if (e != hipSuccess) rc = fail(OIVAE_E_HIP, "oivae_init: uploading the rsqrt14 table failed: %s", hipGetErrorString(e));
+  if (rc == OIVAE_OK) g_tab[device] = d;
+  else if (d) (void)hipFree(d);
+  (void)hipSetDevice(prev);   // also on the error paths
+  return rc;
 }
 
 extern "C" int64_t oivae_workspace_bytes(const oivae_shape_t* shape, int64_t B, int32_t S) {

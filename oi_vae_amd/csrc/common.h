@@ -48,6 +48,7 @@ struct Workspace {
   float*  flat;                            // flat (many-small-groups) decoder: Hc | Wc | Wk | Ct | dz partials
   uint32_t* x3_z;                          // x3 decoder: split image of z, 24 KB per 32 rows
   uint32_t* x3_img;                        // x3 encoder: split image of the weights (fwd) / of dpre (bwd)
+  uint32_t* ranges;                        // 64 words: operand maxima of the fp16 kernels (x3_encoder.hip "ranges")
   int64_t total_bytes;
 };
 
@@ -101,13 +102,22 @@ int mfma_encoder_fwd_splits(const oivae_shape_t& s, int64_t B);  // mfma_encoder
 // x3_encoder.hip: fp32 GEMMs as six bf16 matrix products
 bool x3_encoder_applies(const oivae_shape_t& s);
 int64_t x3_encoder_ws_bytes(const oivae_shape_t& s, int64_t B);
-uint32_t* x3_forward_ranges(const float* X, int64_t B, const uint32_t* img);  // ranges recorded by the fp16 forward encoder call, or nullptr
+int64_t x3_encoder_bwd_img_bytes(const oivae_shape_t& s, int64_t B);  // image of dpre^T alone (0 when the x3 backward kernels do not apply)
+uint32_t* x3_forward_ranges(const float* X, int64_t B, uint32_t* rng);  // ranges recorded by the fp16 forward encoder call, or nullptr
 int x3_encoder_fwd_splits(const oivae_shape_t& s, int64_t B);
 bool x3_encoder_bwd_applies(const oivae_shape_t& s, int64_t B);
 int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X, const float* dpre,
-                          int64_t B, uint32_t* img, hipStream_t st);
+                          int64_t B, uint32_t* img, uint32_t* rng, hipStream_t st);
 int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params, const float* X, int64_t B,
-                          float* pre, uint32_t* wimg, int splits, hipStream_t st);
+                          float* pre, uint32_t* wimg, uint32_t* rng, int splits, hipStream_t st);
+// the kernel sequence of oivae_encoder_bwd_f32 on explicit scratch regions (generic.hip): dpre [B, 2K] floats,
+// bias_part [n_bias, 2K] doubles, x3_img x3_encoder_bwd_img_bytes (or the workspace's larger image), rng 64 words
+int encoder_bwd_run(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X, int64_t B, int32_t S,
+                    const float* eps, float c, const float* prior_mu, const float* prior_sigma, int32_t prior_rows,
+                    const float* mu_q, const float* sig_q, const float* ea, const float* dz, float* dpre,
+                    double* bias_part, int n_bias, uint32_t* x3_img, uint32_t* rng, hipStream_t st);
+inline int enc_bias_blocks(int64_t B) { const int64_t bb = (B + 63) / 64; return (int)(bb > kBiasBlocks ? kBiasBlocks : bb); }
+
 void launch_slab_reduce(const float* slab, int64_t P, int chunks, float* dst, int64_t seg_off, int64_t seg_n,
                         unsigned blocks, hipStream_t st);
 

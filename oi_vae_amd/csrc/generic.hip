@@ -542,7 +542,7 @@ extern "C" int oivae_encoder_fwd_f32(const oivae_shape_t* shape, const oivae_ten
   hipStream_t st = (hipStream_t)stream;
   float* pre = w.dpre;  // [B, 2K]; the backward pass reuses the buffer for dpre
   if (x3_encoder_applies(*shape)) {
-    if (int rc = launch_encoder_fwd_x3(*shape, params, X, B, pre, w.x3_img, w.enc_splits, st)) return rc;
+    if (int rc = launch_encoder_fwd_x3(*shape, params, X, B, pre, w.x3_img, w.ranges, w.enc_splits, st)) return rc;
   } else if (mfma_encoder_applies(*shape)) {
     if (int rc = launch_encoder_fwd_mfma(*shape, params, X, B, pre, st)) return rc;
   } else {
@@ -652,23 +652,30 @@ extern "C" int oivae_encoder_bwd_f32(const oivae_shape_t* shape, const oivae_ten
   const oivae_shape_t& s = *shape;
   Workspace w;
   if (int rc = carve_workspace(s, B, S, workspace, workspace_bytes, &w)) return rc;
-  hipStream_t st = (hipStream_t)stream;
+  return encoder_bwd_run(s, grads, X, B, S, eps, c, prior_mu, prior_sigma, prior_rows, mu_q, sig_q, ea, dz, w.dpre,
+                         w.bias_part, w.n_bias, w.x3_img, w.ranges, (hipStream_t)stream);
+}
+
+int oivae::encoder_bwd_run(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X, int64_t B, int32_t S,
+                           const float* eps, float c, const float* prior_mu, const float* prior_sigma, int32_t prior_rows,
+                           const float* mu_q, const float* sig_q, const float* ea, const float* dz, float* dpre,
+                           double* bias_part, int n_bias, uint32_t* x3_img, uint32_t* rng, hipStream_t st) {
   const bool dz_transposed = plan_decoder(s, B * (int64_t)S).mfma;
   const int64_t dz_sn = dz_transposed ? 1 : s.K, dz_sk = dz_transposed ? B * (int64_t)S : 1;
   const size_t pre_lds = sizeof(double) * (2 * (size_t)s.K + 512);
-  hipLaunchKernelGGL(enc_bwd_pre, dim3((unsigned)w.n_bias), dim3(256), pre_lds, st, B, s.K, S, dz, dz_sn, dz_sk, eps, c,
-                     prior_mu, prior_sigma, prior_rows == 1 ? 0 : s.K, mu_q, sig_q, ea, w.dpre, w.bias_part);
+  hipLaunchKernelGGL(enc_bwd_pre, dim3((unsigned)n_bias), dim3(256), pre_lds, st, B, s.K, S, dz, dz_sn, dz_sk, eps, c,
+                     prior_mu, prior_sigma, prior_rows == 1 ? 0 : s.K, mu_q, sig_q, ea, dpre, bias_part);
   OIVAE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(enc_bwd_bias_final, dim3((unsigned)(2 * s.K)), dim3(256), 0, st, w.bias_part, w.n_bias,
+  hipLaunchKernelGGL(enc_bwd_bias_final, dim3((unsigned)(2 * s.K)), dim3(256), 0, st, bias_part, n_bias,
                      s.K, grads->enc_bmu, grads->enc_bsig);
   OIVAE_LAUNCH_CHECK();
   if (x3_encoder_bwd_applies(s, B)) {
-    if (int rc = launch_encoder_bwd_x3(s, grads, X, w.dpre, B, w.x3_img, st)) return rc;
+    if (int rc = launch_encoder_bwd_x3(s, grads, X, dpre, B, x3_img, rng, st)) return rc;
   } else if (mfma_encoder_applies(s)) {
-    if (int rc = launch_encoder_bwd_mfma(s, grads, X, w.dpre, B, st)) return rc;
+    if (int rc = launch_encoder_bwd_mfma(s, grads, X, dpre, B, st)) return rc;
   } else {
     const dim3 grid((unsigned)((s.D + 63) / 64), (unsigned)((2 * s.K + 31) / 32));
-    hipLaunchKernelGGL(enc_bwd_wgrad_generic, grid, dim3(256), 0, st, X, w.dpre, B, s.D, s.K, grads->enc_Wmu,
+    hipLaunchKernelGGL(enc_bwd_wgrad_generic, grid, dim3(256), 0, st, X, dpre, B, s.D, s.K, grads->enc_Wmu,
                        grads->enc_Wsig);
     OIVAE_LAUNCH_CHECK();
   }

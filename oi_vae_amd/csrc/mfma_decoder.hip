@@ -1624,6 +1624,13 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
 // |gmu| <= max c3 times that, |da1| <= max_m sum_d |W2| times that.  A bound may be loose by 2^13 before precision
 // suffers (the scaled maximum only has to stay above 2^0).  Needs the forward encoder call of the same X.
 // ------------------------------------------------------------------------------------------------------------
+// timing-only ablation (tools/dec_ablate.py, never in the shipped library): the dz adds compiled out behind a
+// condition the compiler cannot resolve, so the product itself stays
+#ifdef OIVAE_ABL_NOATOMIC
+#define OIVAE_DZ_ADD(p, v) do { if (a.N < 0) *(p) = (v); } while (0)
+#else
+#define OIVAE_DZ_ADD(p, v) atomicAdd((p), (v))
+#endif
 __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
   constexpr int K = 64, H = 64, M = 64, DG = 64, LW = 65;
   constexpr float kC = 2.885390081777927f;  // 2*log2(e): tanh(x) = 1 - 2/(exp2(kC x) + 1)
@@ -1926,12 +1933,12 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
                  if (u >= 4 && liveRow) {
 #pragma unroll
                    for (int r = 4 * (u - 4); r < 4 * (u - 4) + 4; ++r)
-                     atomicAdd(dzp + (int64_t)(8 * (r >> 2) + (r & 3)) * a.N, dz[0][r] * inv4);
+                     OIVAE_DZ_ADD(dzp + (int64_t)(8 * (r >> 2) + (r & 3)) * a.N, dz[0][r] * inv4);
                  }
                });
       if (liveRow) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(dzp + (int64_t)(32 + 8 * (r >> 2) + (r & 3)) * a.N, dz[1][r] * inv4);
+        for (int r = 0; r < 16; ++r) OIVAE_DZ_ADD(dzp + (int64_t)(32 + 8 * (r >> 2) + (r & 3)) * a.N, dz[1][r] * inv4);
       }
     }
   } else {
@@ -2089,7 +2096,7 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   const bool force_v1 = dec_env != nullptr && dec_env[0] == 'v' && dec_env[1] == '1';
   const bool use_x3 = dec_env == nullptr || dec_env[0] == 'x' || dec_env[0] == 'p' || dec_env[0] == 'h';
   const bool use_pair = dec_env == nullptr || dec_env[0] == 'p' || dec_env[0] == 'h';
-  uint32_t* rng = x3_forward_ranges(X, B, w.x3_img);
+  uint32_t* rng = x3_forward_ranges(X, B, w.ranges);
   // default: the chain wave on fp16 terms when the fp16 forward encoder call of this X left its ranges, else dec_x3_64p
   const bool use_h = rng != nullptr && s.K == 64 && (dec_env == nullptr || dec_env[0] == 'h');
   if (s.K == 64 && use_x3) {

@@ -732,7 +732,12 @@ bool x3_encoder_bwd_applies(const oivae_shape_t& s, int64_t B) {
 int64_t x3_encoder_ws_bytes(const oivae_shape_t& s, int64_t B) {
   if (!x3_encoder_applies(s)) return 0;
   const int64_t kt = x3_ktiles(s.D), bt = x3_encoder_bwd_applies(s, B) ? (B + 31) / 32 : 0;
-  return (int64_t)x3_rows_pad(2 * s.K) * (kt > bt ? kt : bt) * 48 * 4 + 256;  // 3 x bf16 per element of the larger image + ranges
+  return (int64_t)x3_rows_pad(2 * s.K) * (kt > bt ? kt : bt) * 48 * 4;  // 3 x bf16 per element of the larger image
+}
+
+int64_t x3_encoder_bwd_img_bytes(const oivae_shape_t& s, int64_t B) {
+  if (!x3_encoder_bwd_applies(s, B)) return 0;
+  return (int64_t)x3_rows_pad(2 * s.K) * ((B + 31) / 32) * 48 * 4;
 }
 
 int x3_encoder_fwd_splits(const oivae_shape_t& s, int64_t B) {
@@ -743,22 +748,19 @@ int x3_encoder_fwd_splits(const oivae_shape_t& s, int64_t B) {
   return splits;
 }
 
-// Ranges for the fp16 backward kernel: the last 256 bytes of the image region.  [0] = max|X| (bits) recorded by the
+// Ranges of the fp16 kernels: 64 words of the workspace (Workspace::ranges).  [0] = max|X| (bits) recorded by the
 // forward kernel, [2] = max|dpre|.  The host remembers which forward call filled [0]: the backward call takes the fp16
 // kernel only for the same X, batch and workspace (entry points are called from one thread).
-static inline uint32_t* x3_ranges(const oivae_shape_t& s, int64_t B, uint32_t* img) {
-  return img + (x3_encoder_ws_bytes(s, B) - 256) / 4;
-}
 // test hook: OIVAE_ENC=bf16 keeps the three-term bf16 backward kernel
 static inline bool h2_enabled() { const char* e = getenv("OIVAE_ENC"); return !(e && e[0] == 'b'); }
-static struct { const float* X; int64_t B; uint32_t* img; uint32_t* rng; } g_last_fwd = {nullptr, 0, nullptr, nullptr};
-// for the decoder: the ranges recorded by the forward call of this X, batch and workspace (its image region), or nullptr
-uint32_t* x3_forward_ranges(const float* X, int64_t B, const uint32_t* img) {
-  return (h2_enabled() && g_last_fwd.X == X && g_last_fwd.B == B && g_last_fwd.img == img) ? g_last_fwd.rng : nullptr;
+static struct { const float* X; int64_t B; uint32_t* rng; } g_last_fwd = {nullptr, 0, nullptr};
+// for the decoder: the ranges recorded by the forward call of this X, batch and workspace, or nullptr
+uint32_t* x3_forward_ranges(const float* X, int64_t B, uint32_t* rng) {
+  return (h2_enabled() && g_last_fwd.X == X && g_last_fwd.B == B && g_last_fwd.rng == rng) ? rng : nullptr;
 }
 
 int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params, const float* X, int64_t B,
-                          float* pre, uint32_t* wimg, int splits, hipStream_t st) {
+                          float* pre, uint32_t* wimg, uint32_t* rng, int splits, hipStream_t st) {
   if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(wimg) & 15))
     return fail(OIVAE_E_ARG, "x3 encoder: X and the workspace must be 16-byte aligned");
   const int J = 2 * s.K, Jp = x3_rows_pad(J), KT = x3_ktiles(s.D);
@@ -768,7 +770,6 @@ int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int klen = ((KT + splits - 1) / splits) * 32;
   const dim3 grid((unsigned)((B + 127) / 128), (unsigned)(Jp / 128), (unsigned)splits);
-  uint32_t* rng = x3_ranges(s, B, wimg);
   OIVAE_HIP_CHECK(hipMemsetAsync(rng, 0, 16, st));   // [0] max|X| of this call, [1] max|W|, [2] max|dpre|, [3] redo flag
   if (h2_enabled()) {
     hipLaunchKernelGGL(absmax_f32, dim3(256), dim3(256), 0, st, params->enc_Wmu, (int64_t)s.K * s.D, rng + 1);
@@ -796,19 +797,18 @@ int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params,
                        rng, (const uint32_t*)nullptr);
     OIVAE_LAUNCH_CHECK();
   }
-  g_last_fwd = {X, B, wimg, rng};
+  g_last_fwd = {X, B, rng};
   return OIVAE_OK;
 }
 
 int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X, const float* dpre,
-                          int64_t B, uint32_t* img, hipStream_t st) {
+                          int64_t B, uint32_t* img, uint32_t* rng, hipStream_t st) {
   if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(img) & 15))
     return fail(OIVAE_E_ARG, "x3 encoder: X and the workspace must be 16-byte aligned");
   const int J = 2 * s.K, Jp = x3_rows_pad(J);
   const int BT = (int)((B + 31) / 32);
   const int64_t chunks = (int64_t)Jp * BT * 4;
-  if (h2_enabled() && g_last_fwd.X == X && g_last_fwd.B == B && g_last_fwd.img == img) {
-    uint32_t* rng = x3_ranges(s, B, img);
+  if (h2_enabled() && g_last_fwd.X == X && g_last_fwd.B == B && g_last_fwd.rng == rng) {
     OIVAE_HIP_CHECK(hipMemsetAsync(rng + 2, 0, 4, st));
     hipLaunchKernelGGL(absmax_f32, dim3(256), dim3(256), 0, st, dpre, B * (int64_t)J, rng + 2);
     OIVAE_LAUNCH_CHECK();
