@@ -13,7 +13,8 @@
  *   - every call is asynchronous on `stream` and returns 0 on success or a
  *     nonzero OIVAE_E_* code; oivae_last_error() gives the message (per thread).
  *   - no entry point allocates or frees device memory, except oivae_init, which
- *     uploads a 128 KiB constant table once per device.
+ *     uploads a 128 KiB constant table once per device (and resolves the address of
+ *     the static scratch array of oivae_encoder_bwd_noalloc_f32).
  *   - row-major everywhere.  B = batch rows, S = Monte-Carlo samples,
  *     N = S*B decoder rows (sample-major: row n = s*B + b, lib/oivae.py:53),
  *     K = latent dim, G = groups, H = group input dim, M = generator hidden
@@ -168,6 +169,24 @@ int oivae_encoder_bwd_f32(const oivae_shape_t* shape, const oivae_tensors_t* gra
                           const float* mu_q, const float* sig_q, const float* ea,
                           const float* dz,
                           void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- encoder backward without a workspace ---------------------------------------
+ * No counterpart in the reference.  For callers that can neither allocate device memory nor hand over a
+ * workspace: code under HIP graph capture, tight evaluation/serving loops, harnesses that forbid hipMalloc.
+ * Same arguments, kernels and results (bit for bit) as oivae_encoder_bwd_f32, without `workspace`: the scratch
+ * of its kernels (dpre [B,2K], bias-gradient partials, the split image of dpre^T at the matrix-core shapes)
+ * lives in a static device array of OIVAE_NOALLOC_SCRATCH_BYTES that each GPU holds from oivae_init until the
+ * process ends.  Calls whose scratch would exceed it return OIVAE_E_WORKSPACE (need = 8*B*K bytes for dpre
+ * + 16*K*min(256, ceil(B/64)) for the partials + 192*ceil(2K/128)*128*ceil(B/32) for the image when
+ * 2K % 128 == 0, D % 128 == 0 and B % 32 == 0; e.g. K=64: B <= 8192).  Calls no hipMalloc/hipFree or any
+ * allocating routine; oivae_init(device) must have run.  Every call on a GPU shares that GPU's array: calls
+ * that overlap on one GPU (two streams or threads) race; calls ordered on one stream do not. */
+#define OIVAE_NOALLOC_SCRATCH_BYTES (16u << 20)
+int oivae_encoder_bwd_noalloc_f32(const oivae_shape_t* shape, const oivae_tensors_t* grads,
+                                  const float* X, int64_t B, int32_t S, const float* eps, float c,
+                                  const float* prior_mu, const float* prior_sigma, int32_t prior_rows,
+                                  const float* mu_q, const float* sig_q, const float* ea,
+                                  const float* dz, void* stream);
 
 /* ---- weight prior, group-lasso penalty, scalars ----------------------------
  * Replaces NormalPriorTheta.logprob (lib/oivae.py:15-23): sum over every

@@ -21,7 +21,7 @@ SYMBOLS = [
   "oivae_init", "oivae_last_error", "oivae_version", "oivae_workspace_bytes",
   "oivae_prox_f32", "oivae_sgd_prox_f32", "oivae_prox_cols_f32", "oivae_encoder_fwd_f32",
   "oivae_decoder_fwd_bwd_f32", "oivae_encoder_bwd_f32", "oivae_finalize_f32",
-  "oivae_adam_f32",
+  "oivae_adam_f32", "oivae_encoder_bwd_noalloc_f32",
 ]
 
 
@@ -68,10 +68,12 @@ def load():
   L.oivae_decoder_fwd_bwd_f32.argtypes = [PS, PT, PT, c_vp, c_i64, c_i32, c_vp, c_f, c_vp, c_vp, c_i64, c_vp]
   L.oivae_encoder_bwd_f32.argtypes = [PS, PT, c_vp, c_i64, c_i32, c_vp, c_f, c_vp, c_vp, c_i32,
                                       c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]
+  L.oivae_encoder_bwd_noalloc_f32.argtypes = [PS, PT, c_vp, c_i64, c_i32, c_vp, c_f, c_vp, c_vp, c_i32,
+                                              c_vp, c_vp, c_vp, c_vp, c_vp]
   L.oivae_finalize_f32.argtypes = [PS, PT, PT, c_i64, c_i32, c_f, c_f, c_vp, c_vp, c_i64, c_vp]
   L.oivae_adam_f32.argtypes = [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_i32, c_f, c_vp]
   for name in ("oivae_prox_f32", "oivae_sgd_prox_f32", "oivae_prox_cols_f32", "oivae_encoder_fwd_f32", "oivae_decoder_fwd_bwd_f32",
-               "oivae_encoder_bwd_f32", "oivae_finalize_f32", "oivae_adam_f32"):
+               "oivae_encoder_bwd_f32", "oivae_finalize_f32", "oivae_adam_f32", "oivae_encoder_bwd_noalloc_f32"):
     getattr(L, name).restype = ctypes.c_int
   _lib = L
   return L

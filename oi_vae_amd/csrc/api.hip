@@ -256,6 +256,7 @@ extern "C" int oivae_init(int device) {
   if (e == hipSuccess) e = hipMemcpy(d, oivae_rsqrt14_blob, nbytes, hipMemcpyHostToDevice);
   int rc = OIVAE_OK;
   if (e != hipSuccess) rc = fail(OIVAE_E_HIP, "oivae_init: uploading the rsqrt14 table failed: %s", hipGetErrorString(e));
+  if (rc == OIVAE_OK) rc = noalloc_scratch_setup(device);   // `device` is current here
   if (rc == OIVAE_OK) g_tab[device] = d;
   else if (d) (void)hipFree(d);
   (void)hipSetDevice(prev);   // also on the error paths

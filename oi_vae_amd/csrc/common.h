@@ -117,7 +117,8 @@ int encoder_bwd_run(const oivae_shape_t& s, const oivae_tensors_t* grads, const 
                     const float* mu_q, const float* sig_q, const float* ea, const float* dz, float* dpre,
                     double* bias_part, int n_bias, uint32_t* x3_img, uint32_t* rng, hipStream_t st);
 inline int enc_bias_blocks(int64_t B) { const int64_t bb = (B + 63) / 64; return (int)(bb > kBiasBlocks ? kBiasBlocks : bb); }
-
+// noalloc.hip: resolves the device address of the static scratch array for `device` (which must be current)
+int noalloc_scratch_setup(int device);
 void launch_slab_reduce(const float* slab, int64_t P, int chunks, float* dst, int64_t seg_off, int64_t seg_n,
                         unsigned blocks, hipStream_t st);
 
