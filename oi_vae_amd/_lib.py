@@ -48,11 +48,17 @@ def load():
   global _lib
   if _lib is not None:
     return _lib
-  if not os.path.exists(LIB_PATH):
+  _lib = bind(LIB_PATH)
+  return _lib
+
+
+def bind(path):
+  """ctypes handle of a build of the library with every entry point's signature declared."""
+  if not os.path.exists(path):
     raise OivaeError(
-      "liboivae_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
-      "or `make -C oi_vae_amd/csrc`. There is no CPU fallback." % LIB_PATH)
-  L = ctypes.CDLL(LIB_PATH)
+      "%s is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+      "or `make -C oi_vae_amd/csrc`. There is no CPU fallback." % path)
+  L = ctypes.CDLL(path)
   PS, PT = ctypes.POINTER(Shape), ctypes.POINTER(Tensors)
   L.oivae_init.argtypes = [ctypes.c_int]
   L.oivae_init.restype = ctypes.c_int
@@ -75,7 +81,6 @@ def load():
   for name in ("oivae_prox_f32", "oivae_sgd_prox_f32", "oivae_prox_cols_f32", "oivae_encoder_fwd_f32", "oivae_decoder_fwd_bwd_f32",
                "oivae_encoder_bwd_f32", "oivae_finalize_f32", "oivae_adam_f32", "oivae_encoder_bwd_noalloc_f32"):
     getattr(L, name).restype = ctypes.c_int
-  _lib = L
   return L
 
 

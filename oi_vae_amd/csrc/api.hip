@@ -44,6 +44,26 @@ constexpr int kMaxDevices = 64;
 static uint16_t* g_tab[kMaxDevices] = {nullptr};
 static std::mutex g_init_mu;
 
+static uint32_t* g_err_host[kMaxDevices] = {nullptr};
+static uint32_t* g_err_dev[kMaxDevices] = {nullptr};
+
+uint32_t* error_word_device() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  return g_err_dev[dev];
+}
+
+int poll_error_word(const char* who) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || !g_err_host[dev]) return OIVAE_OK;
+  volatile uint32_t* w = g_err_host[dev];
+  const uint32_t code = *w;
+  if (code == 0) return OIVAE_OK;
+  *w = 0;
+  return fail(OIVAE_E_HIP, "%s: an earlier decoder launch on device %d ran out of its bounded wait for an LDS hand-over "
+              "(code %08x); the results of that step are invalid", who, dev, code);
+}
+
 const uint16_t* rsqrt14_table_device() {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
@@ -257,6 +277,14 @@ extern "C" int oivae_init(int device) {
   int rc = OIVAE_OK;
   if (e != hipSuccess) rc = fail(OIVAE_E_HIP, "oivae_init: uploading the rsqrt14 table failed: %s", hipGetErrorString(e));
   if (rc == OIVAE_OK) rc = noalloc_scratch_setup(device);   // `device` is current here
+  if (rc == OIVAE_OK && !g_err_host[device]) {
+    void* h = nullptr;
+    void* dp = nullptr;
+    e = hipHostMalloc(&h, 64, hipHostMallocMapped);
+    if (e == hipSuccess) { memset(h, 0, 64); e = hipHostGetDevicePointer(&dp, h, 0); }
+    if (e != hipSuccess) rc = fail(OIVAE_E_HIP, "oivae_init: error word: %s", hipGetErrorString(e));
+    else { g_err_host[device] = static_cast<uint32_t*>(h); g_err_dev[device] = static_cast<uint32_t*>(dp); }
+  }
   if (rc == OIVAE_OK) g_tab[device] = d;
   else if (d) (void)hipFree(d);
   (void)hipSetDevice(prev);   // also on the error paths
@@ -296,6 +324,7 @@ extern "C" int oivae_finalize_f32(const oivae_shape_t* shape, const oivae_tensor
   if (!params || !grads || !out || !workspace || B < 1 || S < 1)
     return fail(OIVAE_E_ARG, "oivae_finalize_f32: bad argument");
   if (!(sigma_theta > 0.f)) return fail(OIVAE_E_ARG, "oivae_finalize_f32: sigma_theta must be > 0");
+  if (int rc = poll_error_word("oivae_finalize_f32")) return rc;
   Workspace w;
   if (int rc = carve_workspace(*shape, B, S, workspace, workspace_bytes, &w)) return rc;
   hipStream_t st = (hipStream_t)stream;

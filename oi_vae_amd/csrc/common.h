@@ -31,6 +31,12 @@ inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 // Device pointer to the 65536-entry rsqrt14 table of the current device
 // (uploaded by oivae_init), or nullptr.
 const uint16_t* rsqrt14_table_device();
+// The current device's error word: one word of host-mapped memory that a kernel raises when a bounded wait inside it
+// runs out (mfma_decoder.hip lds_wait_ge).  error_word_device(): the pointer kernels take (nullptr before oivae_init);
+// poll_error_word(): called first by every step entry point -- a raised word fails THAT call with OIVAE_E_HIP (the
+// results of the launch that raised it are invalid) and is cleared.
+uint32_t* error_word_device();
+int poll_error_word(const char* who);
 
 // ---- workspace layout -------------------------------------------------------
 // One flat device buffer, carved identically by every entry point.
@@ -103,7 +109,6 @@ int mfma_encoder_fwd_splits(const oivae_shape_t& s, int64_t B);  // mfma_encoder
 bool x3_encoder_applies(const oivae_shape_t& s);
 int64_t x3_encoder_ws_bytes(const oivae_shape_t& s, int64_t B);
 int64_t x3_encoder_bwd_img_bytes(const oivae_shape_t& s, int64_t B);  // image of dpre^T alone (0 when the x3 backward kernels do not apply)
-uint32_t* x3_forward_ranges(const float* X, int64_t B, uint32_t* rng);  // ranges recorded by the fp16 forward encoder call, or nullptr
 int x3_encoder_fwd_splits(const oivae_shape_t& s, int64_t B);
 bool x3_encoder_bwd_applies(const oivae_shape_t& s, int64_t B);
 int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X, const float* dpre,

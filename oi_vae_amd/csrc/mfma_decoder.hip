@@ -54,7 +54,11 @@ struct MfmaDecArgs {
   float sig_off;
   double* ll_part;
   const uint32_t* zimg;  // dec_x3_64: split image of z (x3_split_z), else unused
-  const uint32_t* rng;   // dec_x3_64h: [0] max|X| (fp16 forward encoder), [5] max|z|
+  const uint32_t* rng;   // dec_x3_64h/g: [0] max|X| the scales assume, [5] max|z|
+  uint32_t* rng_seen;    // dec_x3_64g: max|x| of what the kernel read (atomicMax), or nullptr
+  const uint32_t* gate;  // gated launch: returns at once when *gate == 0 (nullptr: always runs)
+  uint32_t* err;         // the library's error word (host-mapped), raised by a timed-out LDS wait
+  int G;
 };
 
 __device__ __forceinline__ float fast_tanh(float x) {
@@ -1277,9 +1281,22 @@ __global__ __launch_bounds__(256) void dec_x3_64(MfmaDecArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kX3DecLdsP = kX3DecLds + 64;
 
-__device__ __forceinline__ void lds_wait_ge(const volatile uint32_t* f, uint32_t v) {
+// Bounded wait on an LDS counter.  The bound (2^22 polls with s_sleep: > 0.1 s, five orders of magnitude above a
+// hand-over) only ends a wave whose partner died; the wave then raises the library's error word (host-mapped memory,
+// api.hip: the next entry-point call on this device fails with OIVAE_E_HIP) and carries on with whatever the tile
+// holds, so the grid still drains.  OIVAE_TEST_WAIT_LIMIT: scratch build of the test suite that forces the time-out.
+#ifndef OIVAE_TEST_WAIT_LIMIT
+#define OIVAE_TEST_WAIT_LIMIT (1 << 22)
+#endif
+__device__ __forceinline__ void lds_wait_ge(const volatile uint32_t* f, uint32_t v, volatile uint32_t* err) {
   int guard = 0;
-  while (__builtin_amdgcn_readfirstlane(*f) < v && ++guard < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+  while (__builtin_amdgcn_readfirstlane(*f) < v) {
+    if (++guard >= OIVAE_TEST_WAIT_LIMIT) {
+      if (err != nullptr && (threadIdx.x & 63) == 0) *err = 0x4c445357u;   // "LDSW"
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
   asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void lds_post(volatile uint32_t* f, uint32_t v) {
@@ -1467,7 +1484,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) uT[rb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(uT[rb][r]) + 1.0f);
-      lds_wait_ge(f_con, pub);
+      lds_wait_ge(f_con, pub, a.err);
       tr_write(uT[0], 0);
       tr_write(uT[1], 1);
       lds_post(f_pub, ++pub);
@@ -1493,7 +1510,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
                [&](int u) { if (u >= 4) gmu_quarter(0, u - 4); });   // block 0 is complete from unit 4 on
 #pragma unroll
       for (int q = 0; q < 4; ++q) gmu_quarter(1, q);
-      lds_wait_ge(f_con, pub);
+      lds_wait_ge(f_con, pub, a.err);
       tr_write(gT[0], 0);
       tr_write(gT[1], 1);
       lds_post(f_pub, ++pub);
@@ -1511,7 +1528,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
                });
 #pragma unroll
       for (int r = 0; r < 16; ++r) dT[1][r] *= uT[1][r];
-      lds_wait_ge(f_con, pub);
+      lds_wait_ge(f_con, pub, a.err);
       tr_write(dT[0], 0);
       tr_write(dT[1], 1);
       lds_post(f_pub, ++pub);
@@ -1544,14 +1561,14 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
       f32x16 rd[2];
       Frag3 tNf[2][2];
       // ---- t ----
-      lds_wait_ge(f_pub, seen + 1);
+      lds_wait_ge(f_pub, seen + 1, a.err);
       rd[0] = tr_read(0);
       rd[1] = tr_read(1);
       lds_post(f_con, ++seen);
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) { tNf[mb][0] = afrag(rd[mb], 0); tNf[mb][1] = afrag(rd[mb], 1); }
       // ---- gmu: column sums, dW2[d][m] += sum_n gmu[n][d] t[n][m] ----
-      lds_wait_ge(f_pub, seen + 1);
+      lds_wait_ge(f_pub, seen + 1, a.err);
       rd[0] = tr_read(0);
       rd[1] = tr_read(1);
       lds_post(f_con, ++seen);
@@ -1573,7 +1590,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
       Frag3 zn[4];
 #pragma unroll
       for (int f = 0; f < 4; ++f) zn[f] = zfrag_of(tile, 4 + f);
-      lds_wait_ge(f_pub, seen + 1);
+      lds_wait_ge(f_pub, seen + 1, a.err);
       rd[0] = tr_read(0);
       rd[1] = tr_read(1);
       lds_post(f_con, ++seen);
@@ -1613,17 +1630,6 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
 }
 
 
-// ------------------------------------------------------------------------------------------------------------
-// dec_x3_64h: dec_x3_64p with the CHAIN wave on two fp16 terms per operand and three products (x3_split.h "h2"):
-// 96 instead of 192 matrix instructions per tile on the critical path, a 6- instead of 11-instruction split; the
-// weight-gradient wave likewise (48 instead of 96), its accumulators hold sums in scaled units and are scaled back
-// once before the end of the kernel, which is unchanged.
-// fp16 has no exponent range to spare: every chain operand is scaled by a power of two taken from its maximum --
-// the weight images from reductions at set-up, z from a reduction before its image is built (rng[5]), t by 2^13 --
-// or from a bound of it: |mu - x| <= max_d(|b2| + sum_m |W2|) + max|X| (rng[0], recorded by the fp16 forward encoder),
-// |gmu| <= max c3 times that, |da1| <= max_m sum_d |W2| times that.  A bound may be loose by 2^13 before precision
-// suffers (the scaled maximum only has to stay above 2^0).  Needs the forward encoder call of the same X.
-// ------------------------------------------------------------------------------------------------------------
 // timing-only ablation (tools/dec_ablate.py, never in the shipped library): the dz adds compiled out behind a
 // condition the compiler cannot resolve, so the product itself stays
 #ifdef OIVAE_ABL_NOATOMIC
@@ -1631,32 +1637,87 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
 #else
 #define OIVAE_DZ_ADD(p, v) atomicAdd((p), (v))
 #endif
-__global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
+
+// ------------------------------------------------------------------------------------------------------------
+// dec_x3_64g: dec_x3_64p on two fp16 terms per operand, with TWO groups per workgroup so that the sum over groups of
+// dz starts on chip.  (Its one-group predecessor dec_x3_64h, round 1's default, is gone: git history)
+// fp16 terms: every chain operand is scaled by a power of two taken from its maximum -- the weight images from
+// reductions at set-up, z from a reduction before its image is built (rng[5]), t by 2^13 -- or from a bound of it:
+// |mu - x| <= max_d(|b2| + sum_m |W2|) + max|X| (rng[0]), |gmu| <= max c3 times that, |da1| <= max_m sum_d |W2| times
+// that.  A bound may be loose by 2^13 before precision suffers (the scaled maximum only has to stay above 2^0).
+// 96 chain and 48 weight-gradient matrix instructions per row tile and group, a 6-instruction split per operand pair;
+// the weight-gradient accumulators hold sums in scaled units and are scaled back once before the end of the kernel.
+// dz = sum_g is the one reduction of the decoder that crosses workgroups; as float atomics it was 17.2 GB of adds
+// per launch at the chip-wide atomic rate (1.27 of 1.3 TB/s: tools/dec_ablate.py, 13.5 ms with the adds, 10.8
+// without).  Moving a group's dz tile between waves costs as much as the atomics it saves (measured: a rendezvous
+// of two chain waves through LDS 1.2 ms per launch, a fourth published tile drained by the weight-gradient waves
+// 3 ms, ds_add_f32 into a shared LDS tile 17 ms), so here nothing moves: ONE chain wave runs the chains of both
+// groups of its workgroup for the same row tile, one after the other, and the second group's dz product
+// accumulates on top of the first's in the same registers (rescaled by the exact power of two between the two
+// groups' units).  32 atomics per tile and PAIR of groups: half the atomic bytes, no extra traffic.
+//   chain wave c (0..3): row tiles chunk*4 + c, ...; groups in the order (c & 1), 1 - (c & 1); six published tiles
+//     per row tile (t, gmu, da1 of each group) through its one tile buffer;
+//   weight-gradient wave (p, grp) = 2 p + grp: group grp's tiles of chain waves 2 p + grp (which does grp first)
+//     and 2 p + 1 - grp (second), alternately, so that both consumers of a chain pair are busy all the time; it holds
+//     group grp's dW2 and P partials over those two row streams.
+// LDS for two groups' weights: the image of A^T is gone, the dz product reads the forward image of A with
+// ds_read_b64_tr_b16 (tools/probe/tr_image_probe.hip: same fragments bit for bit; no measurable cost), which leaves
+// 3 x 16 KB per group; kC moves from the image into the tanh argument's scale.
+// The chain waves also record max|x| of what they read (a.rng_seen): the host's guard compares its power of two
+// with the one the scales were built from (a.rng[0]) and repeats the launch when they differ, so the result never
+// depends on a stale range (launch_decoder_mfma).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kPairImg = 2 * 3 * 4096;   // dwords: [group][A | W2 | W2^T][2 rb][4 ks][2 terms][64 lanes][4]
+constexpr int kPairVec = 2 * 192;        // floats: per group b1, b2, c3 in scaled units
+constexpr int kPairTile = 32 * 68;       // floats: one chain wave's published tile
+constexpr int kPairScr = 3 * 64 * 65 + 128;   // set-up staging 3 x [64][65]; row loop: four tiles
+constexpr int kPairLds = (kPairImg + kPairVec + kPairScr + 64) * 4;
+static_assert(kPairScr >= 4 * kPairTile, "tiles");
+static_assert(kPairImg >= 2 * 4096 + 3 * 64 * 65 + 2 * 192, "end-of-kernel staging");
+
+typedef short x3_s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t x3_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ x3_u32x2 lds_read_tr16(const char* p) {
+  return __builtin_bit_cast(x3_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) x3_s16x4*)(const_cast<char*>(p))));
+}
+
+__global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
   constexpr int K = 64, H = 64, M = 64, DG = 64, LW = 65;
   constexpr float kC = 2.885390081777927f;  // 2*log2(e): tanh(x) = 1 - 2/(exp2(kC x) + 1)
+  constexpr float kSt = 8192.0f;            // t lies in (-1, 1)
+  if (a.gate != nullptr && *a.gate == 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  uint32_t* img = reinterpret_cast<uint32_t*>(smem_raw);   // [4][2 rb][4 ks][3 terms][64 lanes][4 dwords]
-  float* sb1 = reinterpret_cast<float*>(img + 4 * 6144);   // kC * b1
-  float* sb2 = sb1 + 64;
-  float* sC3 = sb2 + 64;                                   // inv / sigma_d^2
-  float* scr = sC3 + 64;                                   // 3 x [64][65] fp32 staging
-  volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(scr + 3 * 64 * LW);  // [4 streams][published, consumed]
+  uint32_t* img = reinterpret_cast<uint32_t*>(smem_raw);
+  float* vec = reinterpret_cast<float*>(img + kPairImg);
+  float* scr = vec + kPairVec;
+  volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(scr + kPairScr);
+  // flags: [2 c], [2 c + 1] tiles published / consumed of chain wave c; [16 + 5 q ..] group q's maxima;
+  // [26] max|x| seen by this workgroup
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-  const int g = blockIdx.x, chunk = blockIdx.y, nchunks = gridDim.y;
+  const int pairIdx = blockIdx.x, chunk = blockIdx.y, nchunks = gridDim.y;
   const bool chainw = wave < 4;
   const int sw = wave & 3;
-  constexpr float kSt = 8192.0f;   // t lies in (-1, 1)
-  float s0 = 1.f, s1 = 1.f, s2 = 1.f, sz = 1.f, sg = 1.f, sd = 1.f, inv1 = 1.f, inv2 = 1.f, inv3 = 1.f, inv4 = 1.f;
-  float invW = 1.f, invP = 1.f, invG = 1.f, invD = 1.f, omtC = 1.f;   // 1/sg, 1/sd, inv3 sd   // the weight-gradient accumulators' units: 1 / (sg 2^13) and 1 / (sd sz)
-  {
+  const int ngrp = (2 * pairIdx + 1 < a.G) ? 2 : 1;   // G odd: the last workgroup has one group
+  // per group of the pair (index q): scales of the chain (chain waves) and of the accumulated sums (weight-gradient waves)
+  float inv1[2] = {1.f, 1.f}, inv2[2] = {1.f, 1.f}, inv4[2] = {1.f, 1.f}, omtC[2] = {1.f, 1.f};
+  float invW[2] = {1.f, 1.f}, invP[2] = {1.f, 1.f}, invG[2] = {1.f, 1.f}, invD[2] = {1.f, 1.f};
+  if (tid < 64) flags[tid] = 0;
+  for (int q = 0; q < 2; ++q) {   // set-up of the pair's groups, one after the other through the same staging
+    const int gq = 2 * pairIdx + q;
+    if (gq >= a.G) break;
+    float* sb1 = vec + 192 * q;
+    float* sb2 = sb1 + 64;
+    float* sC3 = sb2 + 64;
     float* tW1 = scr;
     float* tWs = scr + 64 * LW;
     float* tW2 = scr + 2 * 64 * LW;
-    const float* Wsg = a.Ws + (int64_t)g * K * H;
-    const float* W1g = a.W1 + (int64_t)g * M * H;
-    const float* W2g = a.W2 + (int64_t)g * DG * M;
+    const float* Wsg = a.Ws + (int64_t)gq * K * H;
+    const float* W1g = a.W1 + (int64_t)gq * M * H;
+    const float* W2g = a.W2 + (int64_t)gq * DG * M;
+    __syncthreads();
     for (int i = tid; i < 4096; i += 512) {
       const int o = (i >> 6) * LW + (i & 63);
       tW1[o] = W1g[i];
@@ -1664,12 +1725,11 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
       tW2[o] = W2g[i];
     }
     if (tid < 64) {
-      const float sg = expf(a.ls[(int64_t)g * DG + tid]) + a.sig_off;
-      sb1[tid] = kC * a.b1[(int64_t)g * M + tid];
-      sb2[tid] = a.b2[(int64_t)g * DG + tid];
-      sC3[tid] = (a.inv / sg) / sg;
+      const float sig = expf(a.ls[(int64_t)gq * DG + tid]) + a.sig_off;
+      sb1[tid] = a.b1[(int64_t)gq * M + tid];
+      sb2[tid] = a.b2[(int64_t)gq * DG + tid];
+      sC3[tid] = (a.inv / sig) / sig;
     }
-    if (tid < 16) flags[tid] = 0;
     __syncthreads();
     // A[m][k] = sum_h W1[m][h] Ws[k][h] on the fp32 matrix instruction, one 32 x 32 block per chain wave
     f32x16 acc = (f32x16)(0.f);
@@ -1678,7 +1738,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
       const float* pa = tW1 + (32 * mt + l31) * LW + hh;
       const float* pb = tWs + (32 * kt + l31) * LW + hh;
 #pragma unroll 8
-      for (int s2 = 0; s2 < 32; ++s2) acc = mf32(pa[2 * s2], pb[2 * s2], acc);
+      for (int k2 = 0; k2 < 32; ++k2) acc = mf32(pa[2 * k2], pb[2 * k2], acc);
     }
     __syncthreads();
     if (chainw) {
@@ -1687,8 +1747,13 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
     }
     __syncthreads();
     const float* A = tW1;
-    // ---- ranges: every fp16 operand gets a power-of-two scale from its maximum or from a bound of it ----
-    uint32_t* red = const_cast<uint32_t*>(flags) + 9;   // [0] max|A| [1] max|W2| [2] max_d(|b2| + sum_m |W2|) [3] max_m sum_d |W2| [4] max c3
+    // ranges: [0] max|A|  [1] max|W2|  [2] bound of |gmu|  [3] bound of |da1|.  The bounds are formed dimension by
+    // dimension -- |gmu_d| <= c3_d (|b2_d| + sum_m |W2_dm| + max|X|), |da1_m| <= sum_d |W2_dm| (bound of gmu_d) -- and not
+    // as products of maxima over different dimensions: one output dimension with a huge weight row and a wide sigma
+    // beside ordinary ones made that product loose by 2^19, more than the 2^13 the fp16 terms can absorb
+    // (tests/test_gpu_x3.py, case huge_w2_row).
+    uint32_t* red = const_cast<uint32_t*>(flags) + 16 + 5 * q;
+    float* gbound = scr + 3 * 64 * LW;   // [64]
     {
       float mA = 0.f, mW = 0.f;
       for (int i = tid; i < 4096; i += 512) {
@@ -1699,100 +1764,106 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
       atomicMax(red + 0, __float_as_uint(mA));
       atomicMax(red + 1, __float_as_uint(mW));
       if (tid < 64) {
-        float rs = fabsf(sb2[tid]);
+        float rs = fabsf(sb2[tid]) + __uint_as_float(a.rng[0]);
         for (int m = 0; m < 64; ++m) rs += fabsf(tW2[tid * LW + m]);
-        atomicMax(red + 2, __float_as_uint(rs));
-        atomicMax(red + 4, __float_as_uint(sC3[tid]));
-      } else if (tid < 128) {
-        float cs = 0.f;
-        for (int d = 0; d < 64; ++d) cs += fabsf(tW2[d * LW + (tid - 64)]);
-        atomicMax(red + 3, __float_as_uint(cs));
+        const float gb = sC3[tid] * rs;
+        gbound[tid] = gb;
+        atomicMax(red + 2, __float_as_uint(gb));
       }
     }
     __syncthreads();
+    if (tid < 64) {
+      float cs = 0.f;
+      for (int d = 0; d < 64; ++d) cs += fabsf(tW2[d * LW + tid]) * gbound[d];
+      atomicMax(red + 3, __float_as_uint(cs));
+    }
+    __syncthreads();
+    float q1, q2, qz, qg, qd, i1, i2, iz, ig, id;
     {
       const float mA = __uint_as_float(red[0]), mW = __uint_as_float(red[1]);
-      const float rmax = __uint_as_float(red[2]) + __uint_as_float(a.rng[0]);
-      const float gmax = __uint_as_float(red[4]) * rmax, dmax = __uint_as_float(red[3]) * gmax;
-      float i0, i1, i2, iz, ig, id;
-      h2_scale_of(__float_as_uint(kC * mA), &s0, &i0);
-      h2_scale_of(__float_as_uint(mA), &s1, &i1);
-      h2_scale_of(__float_as_uint(mW), &s2, &i2);
-      h2_scale_of(a.rng[5], &sz, &iz);
-      h2_scale_of(__float_as_uint(gmax), &sg, &ig);
-      h2_scale_of(__float_as_uint(dmax), &sd, &id);
-      inv1 = i0 * iz; inv2 = i2 * (1.0f / kSt); inv3 = i2 * ig; inv4 = i1 * id;
-      invW = ig * (1.0f / kSt); invP = id * iz;
-      invG = ig; invD = id; omtC = inv3 * sd;
+      const float gmax = __uint_as_float(red[2]), dmax = __uint_as_float(red[3]);
+      h2_scale_of(__float_as_uint(mA), &q1, &i1);
+      h2_scale_of(__float_as_uint(mW), &q2, &i2);
+      h2_scale_of(a.rng[5], &qz, &iz);
+      h2_scale_of(__float_as_uint(gmax), &qg, &ig);
+      h2_scale_of(__float_as_uint(dmax), &qd, &id);
     }
+    auto uni = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };   // scalar registers
+    inv1[q] = uni(kC * (i1 * iz)); inv2[q] = uni(i2 * (1.0f / kSt)); inv4[q] = uni(i1 * id);
+    invW[q] = uni(ig * (1.0f / kSt)); invP[q] = uni(id * iz);
+    invG[q] = uni(ig); invD[q] = uni(id); omtC[q] = uni((i2 * ig) * qd);
     __syncthreads();   // every thread has read the maxima before the biases change
     if (tid < 64) {
-      sb1[tid] *= s0 * sz;    // accumulator initial values in the products' scaled units
-      sb2[tid] *= s2 * kSt;
-      sC3[tid] *= sg;         // gmu is produced in its operand's scaled units
+      sb1[tid] *= q1 * qz;    // accumulator initial values in the products' scaled units
+      sb2[tid] *= q2 * kSt;
+      sC3[tid] *= qg;         // gmu is produced in its operand's scaled units
     }
-    {  // the four images in two fp16 terms: item = (row r, step ks, lane half h2) -> 8 slots -> two 16-byte terms
-      const int item = tid;
-      const int r = item >> 3, ks = (item >> 1) & 3, h2 = item & 1;
-      float v[4][8];
+    {  // the three images in two fp16 terms: item = (row r, step ks, lane half h2) -> 8 slots -> two 16-byte terms
+      const int r = tid >> 3, ks = (tid >> 1) & 3, h2 = tid & 1;
+      float v[3][8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int c = x3_slot_feature(ks, h2, e);
-        v[0][e] = (kC * s0) * A[r * LW + c];
-        v[1][e] = s1 * A[c * LW + r];
-        v[2][e] = s2 * tW2[r * LW + c];
-        v[3][e] = s2 * tW2[c * LW + r];
+        v[0][e] = q1 * A[r * LW + c];
+        v[1][e] = q2 * tW2[r * LW + c];
+        v[2][e] = q2 * tW2[c * LW + r];
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const Frag2 f = split8_h2(v[q][0], v[q][1], v[q][2], v[q][3], v[q][4], v[q][5], v[q][6], v[q][7]);
+      for (int w = 0; w < 3; ++w) {
+        const Frag2 f = split8_h2(v[w][0], v[w][1], v[w][2], v[w][3], v[w][4], v[w][5], v[w][6], v[w][7]);
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-          *reinterpret_cast<x3_u32x4*>(img + q * 4096 + ((((r >> 5) * 4 + ks) * 2 + p) * 64 + h2 * 32 + (r & 31)) * 4) = f.p[p];
+          *reinterpret_cast<x3_u32x4*>(img + (q * 3 + w) * 4096 + ((((r >> 5) * 4 + ks) * 2 + p) * 64 + h2 * 32 + (r & 31)) * 4) = f.p[p];
       }
     }
-    __syncthreads();
   }
-  const uint32_t* imgl = img + lane * 4;
-  auto wfrag = [&](int which, int rb, int ks) {
+  __syncthreads();
+  auto wfrag = [&](const uint32_t* imgl, int which, int rb, int ks) {
     Frag2 f;
 #pragma unroll
     for (int p = 0; p < 2; ++p) f.p[p] = *reinterpret_cast<const x3_u32x4*>(imgl + which * 4096 + ((rb * 4 + ks) * 2 + p) * 256);
     return f;
   };
+  // The dz product needs A with lane = latent k and slots = hidden m.  Transposed reads of the forward image: per 16
+  // lanes a block of 4 rows (m) x 16 columns (k); lane 4 qq + pp of the group addresses (row qq, columns 4 pp .. +3),
+  // lane i receives column i.  Group (lane >> 4): k = 32 rb + 16 (group & 1) + i, m = 16 ks + 8 j + 4 hh + qq.
+  const int tr_lane = ((lane >> 4) & 1) * 2048 + ((lane & 1) * 32 + 4 * hh + ((lane >> 2) & 3)) * 16 + ((lane >> 1) & 1) * 8;
+  auto wfrag_tr = [&](const char* trb, int rb, int ks) {
+    Frag2 f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const x3_u32x2 v = lds_read_tr16(trb + ((((ks >> 1) * 4 + 2 * rb) * 2 + p) * 1024 + (16 * (ks & 1) + 8 * j) * 16));
+        f.p[p][2 * j] = v[0];
+        f.p[p][2 * j + 1] = v[1];
+      }
+    return f;
+  };
   auto afrag2n = [&](const f32x16& v, int q) {   // values already in scaled units
     return split8_h2(v[8 * q], v[8 * q + 1], v[8 * q + 2], v[8 * q + 3], v[8 * q + 4], v[8 * q + 5], v[8 * q + 6], v[8 * q + 7]);
   };
-  auto afrag2 = [&](const f32x16& v, int q, float sc) {
-    return split8_h2(v[8 * q] * sc, v[8 * q + 1] * sc, v[8 * q + 2] * sc, v[8 * q + 3] * sc, v[8 * q + 4] * sc,
-                     v[8 * q + 5] * sc, v[8 * q + 6] * sc, v[8 * q + 7] * sc);
-  };
-  auto afrag = [&](const f32x16& v, int q) {
-    return split8(v[8 * q], v[8 * q + 1], v[8 * q + 2], v[8 * q + 3], v[8 * q + 4], v[8 * q + 5], v[8 * q + 6], v[8 * q + 7]);
-  };
-  // One chained product, both 32-row output blocks, as eight pinned units (u = 4 rb + ks) of six MFMAs: the weight
-  // fragments of unit u+2 are requested and the operand of step u+1 is split inside unit u's region, so that LDS
-  // latency and the split's vector work sit under MFMAs already issued (left to itself the scheduler requests a
-  // fragment one MFMA before its use and waits for it).  `side(u)`: independent work to place in unit u.
-  auto chain_mm = [&](f32x16* acc, int which, Frag2* bf, auto&& make, auto&& side) {
+  // One chained product, both 32-row output blocks, as eight pinned units (u = 4 rb + ks) of three MFMAs: the weight
+  // fragments of unit u+2 are requested and the operand of step u+1 is split inside unit u's region (dec_x3_64p).
+  auto chain_mm = [&](f32x16* acc, auto&& wf, Frag2* bf, auto&& make, auto&& side) {
     Frag2 w[3];
-    w[0] = wfrag(which, 0, 0);
-    w[1] = wfrag(which, 0, 1);
+    w[0] = wf(0, 0);
+    w[1] = wf(0, 1);
     bf[0] = make(0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      if (u + 2 < 8) w[(u + 2) % 3] = wfrag(which, (u + 2) >> 2, (u + 2) & 3);
+      if (u + 2 < 8) w[(u + 2) % 3] = wf((u + 2) >> 2, (u + 2) & 3);
       if (u + 1 < 4) bf[u + 1] = make(u + 1);
       side(u);
       h2mm(acc[u >> 2], w[u % 3], bf[u & 3]);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto init_t = [&](f32x16& acc, const float* vec, int rb) {
+  auto init_t = [&](f32x16& acc, const float* v0, int rb) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(vec + 32 * rb + 8 * q + 4 * hh);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(v0 + 32 * rb + 8 * q + 4 * hh);
       acc[4 * q] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
     }
   };
@@ -1803,31 +1874,8 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
     for (int p = 0; p < 2; ++p) r.p[p] = *reinterpret_cast<const x3_u32x4*>(zi + (f * 2 + p) * 256);
     return r;
   };
-  auto zfrag_of = [&](int t, int f) {
-    Frag3 r;
-    const uint32_t* zi = a.zimg + ((int64_t)t * 24 * 64 + lane) * 4;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) r.p[p] = *reinterpret_cast<const x3_u32x4*>(zi + (f * 3 + p) * 256);
-    return r;
-  };
-  // the stream's fp32 tile [32 rows][68]: written 16 bytes at a time with lane = batch row, read with lane = feature
+  // a chain wave's fp32 tile [32 rows][68]: written 16 bytes at a time with lane = batch row, read with lane = feature
   constexpr int LT = 68;
-  float* tr = scr + sw * (32 * LT);
-  float* trw = tr + l31 * LT + 4 * hh;
-  const float* trr = tr + (4 * hh) * LT + l31;
-  auto tr_write = [&](const f32x16& v, int rb) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<f32x4*>(trw + 32 * rb + 8 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-  };
-  auto tr_read = [&](int cb) {
-    f32x16 v;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = trr[(8 * (r >> 2) + (r & 3)) * LT + 32 * cb];
-    return v;
-  };
-  volatile uint32_t* f_pub = flags + 2 * sw;
-  volatile uint32_t* f_con = flags + 2 * sw + 1;
 
   const int N32 = (int)a.N;
   const int ntiles = (N32 + 31) / 32;
@@ -1838,11 +1886,24 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) { dW2a[i][j] = (f32x16)(0.f); Pa[i][j] = (f32x16)(0.f); }
   float sg1[2] = {0.f, 0.f}, sg2[2] = {0.f, 0.f}, sd1[2] = {0.f, 0.f};
+  float xm = 0.f;
+  const int wgrp = sw & 1, wp = sw >> 1;   // weight-gradient wave (wp, wgrp): group wgrp of chain waves 2 wp, 2 wp + 1
+  const bool active = chainw || wgrp < ngrp;
 
   if (chainw) {
     // =============================== chain wave ===============================
     __builtin_amdgcn_s_setprio(3);   // the critical path of the pair: issue before the other wave of the SIMD
+    float* trw = scr + sw * kPairTile + l31 * LT + 4 * hh;
+    auto tr_write = [&](const f32x16& v, int rb) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(trw + 32 * rb + 8 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    };
+    volatile uint32_t* f_pub = flags + 2 * sw;
+    volatile uint32_t* f_con = flags + 2 * sw + 1;
     uint32_t pub = 0;
+    char* const dzb = reinterpret_cast<char*>(a.dzT);
+    const int64_t rowbytes = a.N * 4;
     Frag2 zf[4];
     if (chunk * 4 + sw < ntiles) {
 #pragma unroll
@@ -1853,160 +1914,214 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
       const int r0 = tile * 32;
       const int nT = (r0 + l31 < N32) ? r0 + l31 : N32 - 1;
       const float liveT = (r0 + l31 < N32) ? 1.0f : 0.0f;
-      const float* xT = a.X + (one_sample ? (int64_t)nT : (int64_t)nT % a.B) * (int64_t)a.D + (int64_t)g * DG + 4 * hh;
-      f32x4 xq[2][4];
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xq[rb][q] = *reinterpret_cast<const f32x4*>(xT + 32 * rb + 8 * q);
-      // ---- kC (a1 + b1) in units of 1 / inv1 ----
-      f32x16 uT[2];
-      init_t(uT[0], sb1, 0);
-      init_t(uT[1], sb1, 1);
-      auto none = [&](int) {};
-      chain_mm(uT, 0, zf, [&](int ks) { return zf[ks]; }, none);
-      // ---- t = tanh: published first, split during the next product ----
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          uT[rb][r] = fmaf(-2.0f * kSt, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(uT[rb][r] * inv1) + 1.0f), kSt);   // 2^13 t
-      lds_wait_ge(f_con, pub);
-      tr_write(uT[0], 0);
-      tr_write(uT[1], 1);
-      lds_post(f_pub, ++pub);
-      // ---- mu = W2 t + b2; gmu = (mu - x) inv / sigma^2; afterwards uT holds inv3 (1 - t^2) ----
-      Frag2 tf[4];
-      f32x16 gT[2];
-      init_t(gT[0], sb2, 0);
-      init_t(gT[1], sb2, 1);
-      auto gmu_quarter = [&](int rb, int q) {
-        const f32x4 c3 = *reinterpret_cast<const f32x4*>(sC3 + 32 * rb + 8 * q + 4 * hh);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) gT[rb][4 * q + i] = fmaf(gT[rb][4 * q + i], inv2, -xq[rb][q][i]) * (c3[i] * liveT);
-      };
-      chain_mm(gT, 2, tf,
-               [&](int ks) {
-                 const Frag2 f = afrag2n(uT[ks >> 1], ks & 1);
-                 if (ks & 1) {
-#pragma unroll
-                   for (int r = 0; r < 16; ++r) uT[ks >> 1][r] = fmaf(-(omtC / (kSt * kSt)) * uT[ks >> 1][r], uT[ks >> 1][r], omtC);
-                 }
-                 return f;
-               },
-               [&](int u) { if (u >= 4) gmu_quarter(0, u - 4); });
-#pragma unroll
-      for (int q = 0; q < 4; ++q) gmu_quarter(1, q);
-      lds_wait_ge(f_con, pub);
-      tr_write(gT[0], 0);
-      tr_write(gT[1], 1);
-      lds_post(f_pub, ++pub);
-      // ---- dt = W2^T gmu; da1 = dt (1 - t^2) ----
-      Frag2 gf[4];
-      f32x16 dT[2];
-      dT[0] = (f32x16)(0.f);
-      dT[1] = (f32x16)(0.f);
-      chain_mm(dT, 3, gf, [&](int ks) { return afrag2n(gT[ks >> 1], ks & 1); },
-               [&](int u) {
-                 if (u >= 4) {
-#pragma unroll
-                   for (int r = 4 * (u - 4); r < 4 * (u - 4) + 4; ++r) dT[0][r] *= uT[0][r];
-                 }
-               });
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dT[1][r] *= uT[1][r];
-      lds_wait_ge(f_con, pub);
-      tr_write(dT[0], 0);
-      tr_write(dT[1], 1);
-      lds_post(f_pub, ++pub);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) zf[ks] = zfrag2_of(tnext, ks);   // the next tile's first operand, one product ahead
-      // ---- dz^T[k][n] += sum_m A[m][k] da1[n][m] ----
-      Frag2 df[4];
+      const float* xrow = a.X + (one_sample ? (int64_t)nT : (int64_t)nT % a.B) * (int64_t)a.D + 4 * hh;
       f32x16 dz[2];
       dz[0] = (f32x16)(0.f);
       dz[1] = (f32x16)(0.f);
-      float* dzp = a.dzT + (int64_t)(4 * hh) * a.N + nT;
-      const bool liveRow = r0 + l31 < N32;
-      chain_mm(dz, 1, df, [&](int ks) { return afrag2n(dT[ks >> 1], ks & 1); },
-               [&](int u) {
-                 if (u >= 4 && liveRow) {
+#pragma unroll 1
+      for (int h = 0; h < ngrp; ++h) {
+        const int q = (ngrp == 2) ? ((sw & 1) ^ h) : 0;   // the group of the pair this half of the tile works on
+        const uint32_t* imgl = img + q * 3 * 4096 + lane * 4;
+        const char* trb = reinterpret_cast<const char*>(img + q * 3 * 4096) + tr_lane;
+        const float* sb1 = vec + 192 * q;
+        const float* sb2 = sb1 + 64;
+        const float* sC3 = sb2 + 64;
+        const float k_inv1 = q ? inv1[1] : inv1[0], k_inv2 = q ? inv2[1] : inv2[0], k_omtC = q ? omtC[1] : omtC[0];
+        const float* xT = xrow + (int64_t)(2 * pairIdx + q) * DG;
+        f32x4 xq[2][4];
 #pragma unroll
-                   for (int r = 4 * (u - 4); r < 4 * (u - 4) + 4; ++r)
-                     OIVAE_DZ_ADD(dzp + (int64_t)(8 * (r >> 2) + (r & 3)) * a.N, dz[0][r] * inv4);
-                 }
-               });
-      if (liveRow) {
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) OIVAE_DZ_ADD(dzp + (int64_t)(32 + 8 * (r >> 2) + (r & 3)) * a.N, dz[1][r] * inv4);
+          for (int qq = 0; qq < 4; ++qq) xq[rb][qq] = *reinterpret_cast<const f32x4*>(xT + 32 * rb + 8 * qq);
+        // ---- a1 + b1 in units of 1 / (s1 sz) ----
+        f32x16 uT[2];
+        init_t(uT[0], sb1, 0);
+        init_t(uT[1], sb1, 1);
+        auto none = [&](int) {};
+        chain_mm(uT, [&](int rb, int ks) { return wfrag(imgl, 0, rb, ks); }, zf, [&](int ks) { return zf[ks]; }, none);
+        // ---- t = tanh: published first, split during the next product ----
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            uT[rb][r] = fmaf(-2.0f * kSt, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(uT[rb][r] * k_inv1) + 1.0f), kSt);   // 2^13 t
+        lds_wait_ge(f_con, pub, a.err);
+        tr_write(uT[0], 0);
+        tr_write(uT[1], 1);
+        lds_post(f_pub, ++pub);
+        // ---- mu = W2 t + b2; gmu = (mu - x) inv / sigma^2; afterwards uT holds inv3 sd (1 - t^2) ----
+        Frag2 tf[4];
+        f32x16 gT[2];
+        init_t(gT[0], sb2, 0);
+        init_t(gT[1], sb2, 1);
+        auto gmu_quarter = [&](int rb, int qq) {
+          const f32x4 c3 = *reinterpret_cast<const f32x4*>(sC3 + 32 * rb + 8 * qq + 4 * hh);
+          const f32x4 x4 = xq[rb][qq];
+          xm = fmaxf(xm, fmaxf(fmaxf(fabsf(x4[0]), fabsf(x4[1])), fmaxf(fabsf(x4[2]), fabsf(x4[3]))));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) gT[rb][4 * qq + i] = fmaf(gT[rb][4 * qq + i], k_inv2, -x4[i]) * (c3[i] * liveT);
+        };
+        chain_mm(gT, [&](int rb, int ks) { return wfrag(imgl, 1, rb, ks); }, tf,
+                 [&](int ks) {
+                   const Frag2 f = afrag2n(uT[ks >> 1], ks & 1);
+                   if (ks & 1) {
+#pragma unroll
+                     for (int r = 0; r < 16; ++r) uT[ks >> 1][r] = fmaf(-(k_omtC / (kSt * kSt)) * uT[ks >> 1][r], uT[ks >> 1][r], k_omtC);
+                   }
+                   return f;
+                 },
+                 [&](int u) { if (u >= 4) gmu_quarter(0, u - 4); });
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) gmu_quarter(1, qq);
+        lds_wait_ge(f_con, pub, a.err);
+        tr_write(gT[0], 0);
+        tr_write(gT[1], 1);
+        lds_post(f_pub, ++pub);
+        // ---- dt = W2^T gmu; da1 = dt (1 - t^2) ----
+        Frag2 gf[4];
+        f32x16 dT[2];
+        dT[0] = (f32x16)(0.f);
+        dT[1] = (f32x16)(0.f);
+        chain_mm(dT, [&](int rb, int ks) { return wfrag(imgl, 2, rb, ks); }, gf, [&](int ks) { return afrag2n(gT[ks >> 1], ks & 1); },
+                 [&](int u) {
+                   if (u >= 4) {
+#pragma unroll
+                     for (int r = 4 * (u - 4); r < 4 * (u - 4) + 4; ++r) dT[0][r] *= uT[0][r];
+                   }
+                 });
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dT[1][r] *= uT[1][r];
+        lds_wait_ge(f_con, pub, a.err);
+        tr_write(dT[0], 0);
+        tr_write(dT[1], 1);
+        lds_post(f_pub, ++pub);
+        {   // the next first product's operand, one product ahead: the same row tile's for the pair's second group
+          const int tz = (h + 1 < ngrp) ? tile : tnext;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) zf[ks] = zfrag2_of(tz, ks);
+        }
+        // ---- dz^T[k][n] += sum_m A[m][k] da1[n][m], on top of the pair's first group (brought to this group's units) ----
+        if (h == 1) {
+          const float ratio = (q ? inv4[0] : inv4[1]) / (q ? inv4[1] : inv4[0]);   // powers of two: exact
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { dz[0][r] *= ratio; dz[1][r] *= ratio; }
+        }
+        Frag2 df[4];
+        const bool last = h + 1 == ngrp;
+        const float k_inv4 = q ? inv4[1] : inv4[0];
+        // dz^T[k][n] lives at dzT + k N + n: uniform row base (scalar registers) + 32-bit per-lane byte offset
+        // (the row bases are formed next to their use: hoisted out of this loop, the 32 addresses were spilled)
+        uint32_t voff = (uint32_t)((int64_t)(4 * hh) * a.N + nT) * 4u;
+        asm volatile("" : "+v"(voff));
+        const bool liveRow = r0 + l31 < N32;
+        auto dz_row = [&](int row) { return reinterpret_cast<float*>(dzb + (int64_t)row * rowbytes + voff); };
+        chain_mm(dz, [&](int rb, int ks) { return wfrag_tr(trb, rb, ks); }, df, [&](int ks) { return afrag2n(dT[ks >> 1], ks & 1); },
+                 [&](int u) {
+                   if (u >= 4 && last && liveRow) {
+#pragma unroll
+                     for (int r = 4 * (u - 4); r < 4 * (u - 4) + 4; ++r) OIVAE_DZ_ADD(dz_row(8 * (r >> 2) + (r & 3)), dz[0][r] * k_inv4);
+                   }
+                 });
+        if (last && liveRow) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) OIVAE_DZ_ADD(dz_row(32 + 8 * (r >> 2) + (r & 3)), dz[1][r] * k_inv4);
+        }
       }
     }
-  } else {
+  } else if (active) {
     // =============================== weight-gradient wave ===============================
-    uint32_t seen = 0;
-    for (int tile = chunk * 4 + sw; tile < ntiles; tile += 4 * nchunks) {
-      f32x16 rd[2];
-      Frag2 tNf[2][2];
-      // ---- t ----
-      lds_wait_ge(f_pub, seen + 1);
-      rd[0] = tr_read(0);
-      rd[1] = tr_read(1);
-      lds_post(f_con, ++seen);
+    // producer j = 0: chain wave 2 wp + wgrp (this group is the first half of its row tile), j = 1: the other one
+    uint32_t seen[2] = {0, 0};
+    const int npub = 3 * ngrp;
+    for (int t0 = chunk * 4 + 2 * wp; t0 < ntiles; t0 += 4 * nchunks) {
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) { tNf[mb][0] = afrag2n(rd[mb], 0); tNf[mb][1] = afrag2n(rd[mb], 1); }
-      // ---- gmu: column sums, dW2[d][m] += sum_n gmu[n][d] t[n][m] ----
-      lds_wait_ge(f_pub, seen + 1);
-      rd[0] = tr_read(0);
-      rd[1] = tr_read(1);
-      lds_post(f_con, ++seen);
+      for (int j = 0; j < 2; ++j) {
+        const int c = 2 * wp + (j ^ wgrp);           // the chain wave
+        const int tile = t0 - 2 * wp + c;             // its row tile of this round
+        if (tile >= ntiles) continue;
+        const float* trr = scr + c * kPairTile + (4 * hh) * LT + l31;
+        auto tr_read = [&](int cb) {
+          f32x16 v;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float s1 = 0.f, s2 = 0.f;
+          for (int r = 0; r < 16; ++r) v[r] = trr[(8 * (r >> 2) + (r & 3)) * LT + 32 * cb];
+          return v;
+        };
+        volatile uint32_t* f_pub = flags + 2 * c;
+        volatile uint32_t* f_con = flags + 2 * c + 1;
+        uint32_t n = seen[j] + ((ngrp == 2 && j == 1) ? 3 : 0);   // publishes of this chain wave before this group's three
+        seen[j] += npub;
+        f32x16 rd[2];
+        Frag2 tNf[2][2];
+        // ---- t ----
+        lds_wait_ge(f_pub, n + 1, a.err);
+        rd[0] = tr_read(0);
+        rd[1] = tr_read(1);
+        lds_post(f_con, ++n);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s1 += rd[i][r]; s2 = fmaf(rd[i][r], rd[i][r], s2); }
-        sg1[i] += s1;
-        sg2[i] += s2;
-        const Frag2 g0 = afrag2n(rd[i], 0), g1 = afrag2n(rd[i], 1);
+        for (int mb = 0; mb < 2; ++mb) { tNf[mb][0] = afrag2n(rd[mb], 0); tNf[mb][1] = afrag2n(rd[mb], 1); }
+        // ---- gmu: column sums, dW2[d][m] += sum_n gmu[n][d] t[n][m] ----
+        lds_wait_ge(f_pub, n + 1, a.err);
+        rd[0] = tr_read(0);
+        rd[1] = tr_read(1);
+        lds_post(f_con, ++n);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          h2mm(dW2a[i][j], g0, tNf[j][0]);
-          h2mm(dW2a[i][j], g1, tNf[j][1]);
+        for (int i = 0; i < 2; ++i) {
+          float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { c1 += rd[i][r]; c2 = fmaf(rd[i][r], rd[i][r], c2); }
+          sg1[i] += c1;
+          sg2[i] += c2;
+          const Frag2 g0 = afrag2n(rd[i], 0), g1 = afrag2n(rd[i], 1);
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            h2mm(dW2a[i][jj], g0, tNf[jj][0]);
+            h2mm(dW2a[i][jj], g1, tNf[jj][1]);
+          }
+        }
+        // ---- da1: column sums, P[m][k] += sum_n da1[n][m] z[n][k] (z's fragments requested before the wait) ----
+        Frag2 zn[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) zn[f] = zfrag2_of(tile, 4 + f);
+        lds_wait_ge(f_pub, n + 1, a.err);
+        rd[0] = tr_read(0);
+        rd[1] = tr_read(1);
+        lds_post(f_con, ++n);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float csum = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) csum += rd[i][r];
+          sd1[i] += csum;
+          const Frag2 d0 = afrag2n(rd[i], 0), d1 = afrag2n(rd[i], 1);
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            h2mm(Pa[i][jj], d0, zn[2 * jj]);
+            h2mm(Pa[i][jj], d1, zn[2 * jj + 1]);
+          }
         }
       }
-      // ---- da1: column sums, P[m][k] += sum_n da1[n][m] z[n][k] (z's fragments requested before the wait) ----
-      Frag2 zn[4];
+    }
+    {   // the accumulated weight gradients back into true units
+      const float kW = wgrp ? invW[1] : invW[0], kP = wgrp ? invP[1] : invP[0];
+      const float kG = wgrp ? invG[1] : invG[0], kD = wgrp ? invD[1] : invD[0];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) zn[f] = zfrag2_of(tile, 4 + f);
-      lds_wait_ge(f_pub, seen + 1);
-      rd[0] = tr_read(0);
-      rd[1] = tr_read(1);
-      lds_post(f_con, ++seen);
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float csum = 0.f;
+        for (int j = 0; j < 2; ++j) { dW2a[i][j] *= kW; Pa[i][j] *= kP; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) csum += rd[i][r];
-        sd1[i] += csum;
-        const Frag2 d0 = afrag2n(rd[i], 0), d1 = afrag2n(rd[i], 1);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          h2mm(Pa[i][j], d0, zn[2 * j]);
-          h2mm(Pa[i][j], d1, zn[2 * j + 1]);
-        }
-      }
+      for (int i = 0; i < 2; ++i) { sg1[i] *= kG; sg2[i] *= kG * kG; sd1[i] *= kD; }   // the tiles were in scaled units
     }
   }
-  if (!chainw) {   // the accumulated weight gradients back into true units
+  // ---- end of the kernel ----
+  __syncthreads();
+  // max|x| of the rows and columns this workgroup read: one atomic per workgroup
+  if (chainw) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) { dW2a[i][j] *= invW; Pa[i][j] *= invP; }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { sg1[i] *= invG; sg2[i] *= invG * invG; sd1[i] *= invD; }   // the tiles were in scaled units
+    for (int o = 32; o > 0; o >>= 1) xm = fmaxf(xm, __shfl_xor(xm, o));
+    if (lane == 0) atomicMax(const_cast<uint32_t*>(flags) + 26, __float_as_uint(xm));
   }
   // per-column sums: the two lane halves of a column are added through LDS, lane L then holds column L
-  __syncthreads();
-  float* tmp = scr + 2 * 64 * LW + sw * 384;
+  float* tmp = scr + sw * 384;
   if (!chainw) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -2016,14 +2131,127 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64h(MfmaDecArgs a) {
     }
   }
   __syncthreads();
+  if (tid == 0 && a.rng_seen != nullptr) atomicMax(a.rng_seen, flags[26]);
   const int cb = lane >> 5;
   const float cs_gmu = tmp[(0 * 2 + cb) * 64 + l31] + tmp[(0 * 2 + cb) * 64 + 32 + l31];
   const float cs_gmu2 = tmp[(1 * 2 + cb) * 64 + l31] + tmp[(1 * 2 + cb) * 64 + 32 + l31];
   const float cs_da1 = tmp[(2 * 2 + cb) * 64 + l31] + tmp[(2 * 2 + cb) * 64 + 32 + l31];
-  dec64_finish(a, g, chunk, tid & 255, sw, lane, dW2a, Pa, cs_gmu, cs_gmu2, cs_da1, reinterpret_cast<float*>(img), scr,
-               scr + 64 * LW, !chainw);
+  // Per group: the two streams' partials of dW2 and P summed in a fixed order, dW1 = P Ws and dWs = P^T W1 on the
+  // fp32 matrix instruction (the four weight-gradient waves take a quadrant each), column sums -> db2, dlog_sigma,
+  // db1 and the group's log-likelihood partial.  Staging in the image area: [2][4096] partials | Ws | P | W1 | sums.
+  float* stage = reinterpret_cast<float*>(img);
+  float* uWs = stage + 2 * 4096;
+  float* sP = uWs + 64 * LW;
+  float* uW1 = sP + 64 * LW;
+  float* ssum = uW1 + 64 * LW;   // [2 streams][3][64]
+  const bool worker = !chainw;
+  const int wtid = tid & 255;
+  const int64_t cs = a.chunk_stride * chunk;
+  for (int q = 0; q < 2; ++q) {
+    const int gq = 2 * pairIdx + q;
+    if (gq >= a.G) break;
+    const bool mine = worker && wgrp == q && active;
+    const float* Wsg = a.Ws + (int64_t)gq * K * H;
+    const float* W1g = a.W1 + (int64_t)gq * M * H;
+    auto stage_acc = [&](f32x16 (&acc)[2][2]) {
+      __syncthreads();
+      if (mine) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              stage[wp * 4096 + (32 * i + OIVAE_ROW(r, hh)) * 64 + 32 * j + l31] = acc[i][j][r];
+      }
+      __syncthreads();
+    };
+    stage_acc(dW2a);
+    if (worker) {
+      float* dst = a.gW2 + cs + (int64_t)gq * DG * M;
+      for (int idx = wtid; idx < 4096; idx += 256) dst[idx] = stage[idx] + stage[4096 + idx];
+    }
+    stage_acc(Pa);
+    if (worker) {
+      for (int idx = wtid; idx < 4096; idx += 256) {
+        const int o = (idx >> 6) * LW + (idx & 63);
+        sP[o] = stage[idx] + stage[4096 + idx];
+        uW1[o] = W1g[idx];
+        uWs[o] = Wsg[idx];
+      }
+    }
+    if (mine) {
+      ssum[wp * 192 + lane] = cs_gmu;
+      ssum[wp * 192 + 64 + lane] = cs_gmu2;
+      ssum[wp * 192 + 128 + lane] = cs_da1;
+    }
+    __syncthreads();
+    if (worker) {
+      const int it = sw >> 1, ht = sw & 1;
+      f32x16 acc = (f32x16)(0.f);  // dW1[m][h] = sum_k P[m][k] Ws[k][h]
+      const float* pa = sP + (32 * it + l31) * LW + hh;
+      const float* pb = uWs + hh * LW + 32 * ht + l31;
+#pragma unroll 8
+      for (int k2 = 0; k2 < 32; ++k2) acc = mf32(pa[2 * k2], pb[2 * k2 * LW], acc);
+      float* d1 = a.gW1 + cs + (int64_t)gq * M * H;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d1[(32 * it + OIVAE_ROW(r, hh)) * H + 32 * ht + l31] = acc[r];
+      acc = (f32x16)(0.f);         // dWs[k][h] = sum_m P[m][k] W1[m][h]
+      pa = sP + hh * LW + 32 * it + l31;
+      pb = uW1 + hh * LW + 32 * ht + l31;
+#pragma unroll 8
+      for (int k2 = 0; k2 < 32; ++k2) acc = mf32(pa[2 * k2 * LW], pb[2 * k2 * LW], acc);
+      float* d2 = a.gWs + cs + (int64_t)gq * K * H;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d2[(32 * it + OIVAE_ROW(r, hh)) * H + 32 * ht + l31] = acc[r];
+    }
+    float* sred = stage;   // the partials were consumed before the last barrier
+    if (worker && wtid < 64) {
+      const float s_gmu = ssum[wtid] + ssum[192 + wtid];
+      const float s_gmu2 = ssum[64 + wtid] + ssum[256 + wtid];
+      const float s_da1 = ssum[128 + wtid] + ssum[320 + wtid];
+      const int64_t d = (int64_t)gq * DG + wtid;
+      const float e = expf(a.ls[d]);
+      const float sig = e + a.sig_off;
+      const float c2 = a.inv / sig;
+      const float sumq2 = s_gmu2 / (c2 * c2);
+      const float nrows = (chunk == 0) ? (float)a.N : 0.f;
+      a.gb2[cs + d] = s_gmu;
+      a.gls[cs + d] = (nrows - sumq2) * (e * a.inv / sig);
+      a.gb1[cs + (int64_t)gq * M + wtid] = s_da1;
+      sred[wtid] = nrows * (-0.5f * kLog2Pi - logf(sig)) - 0.5f * sumq2;
+    }
+    __syncthreads();
+    if (worker && wtid == 0) {
+      double tot = 0.0;
+      for (int i = 0; i < 64; ++i) tot += (double)sred[i];
+      a.ll_part[(int64_t)chunk * a.G + gq] = tot;
+    }
+  }
 }
 
+// After a kernel that built its fp16 scales from rng[0] (the max|X| an earlier pass recorded) and recorded the
+// max|x| it read itself in rng[seen]: the result stands only if both maxima have the same power of two, i.e. if the
+// scales are the ones X's own maximum gives.  Otherwise flag rng[flag]: a gated second launch repeats the kernel with
+// rng[0] corrected.  Either way the result is a function of the call's inputs alone.
+__global__ void range_guard(uint32_t* rng, int seen, int flag) {
+  float s0, i0, s1, i1;
+  h2_scale_of(rng[0], &s0, &i0);
+  h2_scale_of(rng[seen], &s1, &i1);
+  rng[flag] = (s0 == s1) ? 0u : 1u;
+  rng[0] = rng[seen];
+}
+void launch_range_guard(uint32_t* rng, int seen, int flag, hipStream_t st) {
+  hipLaunchKernelGGL(range_guard, dim3(1), dim3(1), 0, st, rng, seen, flag);
+}
+
+__global__ __launch_bounds__(256) void gated_zero_f32(float* __restrict__ p, int64_t n, const uint32_t* __restrict__ gate) {
+  if (*gate == 0) return;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    reinterpret_cast<f32x4*>(p)[i] = (f32x4)(0.f);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[4 * n4 + threadIdx.x] = 0.f;
+}
 
 bool mfma_decoder_applies(const oivae_shape_t& s) {
   if (getenv("OIVAE_FORCE_GENERIC")) return false;  // test hook: cross-check the two kernel families
@@ -2094,27 +2322,50 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   // kernel, OIVAE_DEC=x3 the single-wave-per-SIMD split-bf16 kernel, OIVAE_DEC=p the all-bf16 pair; default for the
   // all-64 shape: dec_x3_64h (dec_x3_64p without a matching forward encoder call)
   const bool force_v1 = dec_env != nullptr && dec_env[0] == 'v' && dec_env[1] == '1';
-  const bool use_x3 = dec_env == nullptr || dec_env[0] == 'x' || dec_env[0] == 'p' || dec_env[0] == 'h';
-  const bool use_pair = dec_env == nullptr || dec_env[0] == 'p' || dec_env[0] == 'h';
-  uint32_t* rng = x3_forward_ranges(X, B, w.ranges);
-  // default: the chain wave on fp16 terms when the fp16 forward encoder call of this X left its ranges, else dec_x3_64p
-  const bool use_h = rng != nullptr && s.K == 64 && (dec_env == nullptr || dec_env[0] == 'h');
-  if (s.K == 64 && use_x3) {
+  const bool use_x3 = (dec_env != nullptr && (dec_env[0] == 'x' || dec_env[0] == 'p')) ||
+                      (dec_env == nullptr && N * (int64_t)s.K * 4 >= ((int64_t)1 << 32));
+  const bool use_pair = (dec_env != nullptr && dec_env[0] == 'p') || (dec_env == nullptr && N * (int64_t)s.K * 4 >= ((int64_t)1 << 32));
+  // default for the all-64 shape: dec_x3_64g (two groups per workgroup on fp16 terms); its scales assume the max|X|
+  // that the workspace's ranges hold from the last pass over X (the forward encoder call of this step, or the
+  // previous decoder call) and it checks that assumption against what it reads (range_guard): no host-side memory
+  // of earlier calls.
+  // (its atomics address dz with 32-bit byte offsets: larger launches take the bf16 pair)
+  const bool fits32 = N * (int64_t)s.K * 4 < ((int64_t)1 << 32);
+  const bool use_g = s.K == 64 && fits32 && (dec_env == nullptr || dec_env[0] == 'g');
+  uint32_t* rng = w.ranges;
+  a.G = s.G;
+  a.err = error_word_device();
+  a.gate = nullptr;
+  a.rng_seen = nullptr;
+  if (s.K == 64 && (use_x3 || use_g)) {
     if (!w.x3_z) return fail(OIVAE_E_WORKSPACE, "x3 decoder: no z image in the workspace");
     const int64_t zt = (N + 31) / 32;
-    if (use_h) {
-      OIVAE_HIP_CHECK(hipMemsetAsync(rng + 5, 0, 4, st));
+    if (use_g) {
+      OIVAE_HIP_CHECK(hipMemsetAsync(rng + 5, 0, 12, st));   // [5] max|z|, [6] max|x| the kernel reads, [7] redo flag
       hipLaunchKernelGGL(dec_absmax_f32, dim3(256), dim3(256), 0, st, z, N * 64, rng + 5);
       OIVAE_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(x3_split_z, dim3((unsigned)((zt * 512 + 255) / 256)), dim3(256), 0, st, z, N, w.x3_z, use_h ? rng : (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(x3_split_z, dim3((unsigned)((zt * 512 + 255) / 256)), dim3(256), 0, st, z, N, w.x3_z,
+                       use_g ? rng : (const uint32_t*)nullptr);
     OIVAE_LAUNCH_CHECK();
     a.zimg = w.x3_z;
     a.rng = rng;
-    if (use_h) {
-      OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_x3_64h),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kX3DecLdsP));
-      hipLaunchKernelGGL(dec_x3_64h, dim3((unsigned)s.G, (unsigned)chunks), dim3(512), (size_t)kX3DecLdsP, st, a);
+    if (use_g) {
+      OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_x3_64g),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
+      const dim3 grid((unsigned)((s.G + 1) / 2), (unsigned)chunks);
+      a.rng_seen = rng + 6;
+      hipLaunchKernelGGL(dec_x3_64g, grid, dim3(512), (size_t)kPairLds, st, a);
+      OIVAE_LAUNCH_CHECK();
+      launch_range_guard(rng, 6, 7, st);
+      OIVAE_LAUNCH_CHECK();
+      // the repeat, gated on the guard's flag: dz starts from zero again, every other output is overwritten
+      int64_t zb = (N * 64 / 4 + 255) / 256;
+      if (zb > 2048) zb = 2048;
+      hipLaunchKernelGGL(gated_zero_f32, dim3((unsigned)zb), dim3(256), 0, st, dz, N * 64, (const uint32_t*)(rng + 7));
+      a.rng_seen = nullptr;
+      a.gate = rng + 7;
+      hipLaunchKernelGGL(dec_x3_64g, grid, dim3(512), (size_t)kPairLds, st, a);
     } else if (use_pair) {
       OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_x3_64p),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kX3DecLdsP));

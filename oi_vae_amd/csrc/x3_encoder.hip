@@ -358,7 +358,9 @@ __device__ __forceinline__ void h2_step(f32x16 (&acc)[NI][NJ], const u32x4 (&fa)
 __global__ __launch_bounds__(768, 1) void enc_h2_bwd_gemm(const float* __restrict__ X, int64_t B, int D, int J,
                                                           const uint32_t* __restrict__ Pimg, int BT,
                                                           float* __restrict__ out0, float* __restrict__ out1,
-                                                          const uint32_t* __restrict__ rng) {
+                                                          const uint32_t* __restrict__ rng, uint32_t* __restrict__ rng_seen,
+                                                          const uint32_t* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;  // second launch: only if the guard rejected the first one's scale of X
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint32_t* lds = reinterpret_cast<uint32_t*>(smem_raw);  // [2][kH2Buf]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -420,10 +422,12 @@ __global__ __launch_bounds__(768, 1) void enc_h2_bwd_gemm(const float* __restric
 #pragma unroll
       for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const f32x4*>(xptr[i] + k0);
     };
+    float xmax = 0.f;
     auto xstore = [&](int buf, const f32x4 (&r)[4]) {
       uint32_t* base = lds + buf * kH2Buf;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {  // column i of four consecutive rows (the reduction index) -> LDS row 32 i + c
+        xmax = fmaxf(fmaxf(xmax, fmaxf(fabsf(r[i][0]), fabsf(r[i][1]))), fmaxf(fabsf(r[i][2]), fabsf(r[i][3])));
         const Split2 q0 = split2_pair(r[0][i] * sx, r[1][i] * sx);
         const Split2 q1 = split2_pair(r[2][i] * sx, r[3][i] * sx);
         *reinterpret_cast<u32x2*>(base + xoff + 32 * i * kH2Row) = u32x2{q0.h, q1.h};
@@ -441,6 +445,11 @@ __global__ __launch_bounds__(768, 1) void enc_h2_bwd_gemm(const float* __restric
     };
     for (int t = 0; t < Tr; t += 4) {
       step(t, rx[1]); step(t + 1, rx[2]); step(t + 2, rx[3]); step(t + 3, rx[0]);
+    }
+    if (rng_seen != nullptr) {   // max|x| of what this wave streamed (every tile is stored at least once)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o));
+      if (lane == 0) atomicMax(rng_seen, __float_as_uint(xmax));
     }
   } else {
     // ---------------- consumers ----------------
@@ -748,16 +757,16 @@ int x3_encoder_fwd_splits(const oivae_shape_t& s, int64_t B) {
   return splits;
 }
 
-// Ranges of the fp16 kernels: 64 words of the workspace (Workspace::ranges).  [0] = max|X| (bits) recorded by the
-// forward kernel, [2] = max|dpre|.  The host remembers which forward call filled [0]: the backward call takes the fp16
-// kernel only for the same X, batch and workspace (entry points are called from one thread).
-// test hook: OIVAE_ENC=bf16 keeps the three-term bf16 backward kernel
+// Ranges of the fp16 kernels: 64 words of the workspace (Workspace::ranges), all maxima as fp32 bit patterns:
+//   [0] max|X| of the last pass over X (forward encoder, decoder or backward encoder call, whichever ran last)
+//   [1] max|W| of the encoder weights   [2] max|dpre|   [3] forward redo flag   [4] max|X| the forward kernel assumed
+//   [5] max|z|   [6] max|x| the decoder read, [7] its redo flag   [8] max|x| the backward kernel read, [9] its redo flag
+// A kernel that scales X by [0] records what it reads itself; range_guard (mfma_decoder.hip) compares the two powers
+// of two and a gated second launch repeats the kernel when they differ.  No host-side memory of earlier calls: every
+// entry point is a function of its arguments and computes with the scale of its own X's maximum.
+// test hook: OIVAE_ENC=bf16 keeps the three-term bf16 kernels
 static inline bool h2_enabled() { const char* e = getenv("OIVAE_ENC"); return !(e && e[0] == 'b'); }
-static struct { const float* X; int64_t B; uint32_t* rng; } g_last_fwd = {nullptr, 0, nullptr};
-// for the decoder: the ranges recorded by the forward call of this X, batch and workspace, or nullptr
-uint32_t* x3_forward_ranges(const float* X, int64_t B, uint32_t* rng) {
-  return (h2_enabled() && g_last_fwd.X == X && g_last_fwd.B == B && g_last_fwd.rng == rng) ? rng : nullptr;
-}
+void launch_range_guard(uint32_t* rng, int seen, int flag, hipStream_t st);  // mfma_decoder.hip
 
 int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params, const float* X, int64_t B,
                           float* pre, uint32_t* wimg, uint32_t* rng, int splits, hipStream_t st) {
@@ -797,7 +806,6 @@ int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params,
                        rng, (const uint32_t*)nullptr);
     OIVAE_LAUNCH_CHECK();
   }
-  g_last_fwd = {X, B, rng};
   return OIVAE_OK;
 }
 
@@ -808,8 +816,9 @@ int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, 
   const int J = 2 * s.K, Jp = x3_rows_pad(J);
   const int BT = (int)((B + 31) / 32);
   const int64_t chunks = (int64_t)Jp * BT * 4;
-  if (h2_enabled() && g_last_fwd.X == X && g_last_fwd.B == B && g_last_fwd.rng == rng) {
+  if (h2_enabled()) {
     OIVAE_HIP_CHECK(hipMemsetAsync(rng + 2, 0, 4, st));
+    OIVAE_HIP_CHECK(hipMemsetAsync(rng + 8, 0, 8, st));
     hipLaunchKernelGGL(absmax_f32, dim3(256), dim3(256), 0, st, dpre, B * (int64_t)J, rng + 2);
     OIVAE_LAUNCH_CHECK();
     hipLaunchKernelGGL(h2_split_cols, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, dpre, B, J, Jp, BT, img, rng);
@@ -818,7 +827,15 @@ int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, 
     OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_h2_bwd_gemm),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const dim3 grid((unsigned)(s.D / 128), (unsigned)(Jp / 128), 1);
-    hipLaunchKernelGGL(enc_h2_bwd_gemm, grid, dim3(768), lds, st, X, B, s.D, J, img, BT, grads->enc_Wmu, grads->enc_Wsig, rng);
+    // X is scaled by the max|X| the ranges hold (the forward call of this step recorded it); the kernel records what
+    // it streams itself and the guard repeats it with that maximum if the two powers of two differ
+    hipLaunchKernelGGL(enc_h2_bwd_gemm, grid, dim3(768), lds, st, X, B, s.D, J, img, BT, grads->enc_Wmu, grads->enc_Wsig,
+                       (const uint32_t*)rng, rng + 8, (const uint32_t*)nullptr);
+    OIVAE_LAUNCH_CHECK();
+    launch_range_guard(rng, 8, 9, st);
+    OIVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(enc_h2_bwd_gemm, grid, dim3(768), lds, st, X, B, s.D, J, img, BT, grads->enc_Wmu, grads->enc_Wsig,
+                       (const uint32_t*)rng, (uint32_t*)nullptr, (const uint32_t*)(rng + 9));
     OIVAE_LAUNCH_CHECK();
     return OIVAE_OK;
   }

@@ -1,11 +1,14 @@
 #!/bin/bash
-# Scratch build of the library with -DOIVAE_ABL_<TAG> on the decoder translation unit (timing only; see tools/dec_ablate.py).
+# Scratch build of the library with -DOIVAE_ABL_<TAG> (several tags joined by '+') on the decoder translation unit
+# (timing only; see tools/dec_ablate.py).
 set -euo pipefail
-TAG="$1"
+TAGS="$1"
 HERE="$(cd "$(dirname "$0")/.." && pwd)"
 C="$HERE/oi_vae_amd/csrc"
 mkdir -p "$HERE/tools/probe"
-/opt/rocm/bin/hipcc -O3 -fno-slp-vectorize -fPIC --offload-arch=gfx950 -std=c++17 -DOIVAE_ABL_$TAG -c "$C/mfma_decoder.hip" -o "$HERE/tools/probe/abl_$TAG.o"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$C/build/api.o" "$C/build/prox.o" "$C/build/generic.o" "$HERE/tools/probe/abl_$TAG.o" \
-  "$C/build/mfma_encoder.o" "$C/build/flat_decoder.o" "$C/build/x3_encoder.o" -o "$HERE/tools/probe/liboivae_abl_$TAG.so"
-rm -f "$HERE/tools/probe/abl_$TAG.o"
+DEFS=""
+for t in ${TAGS//+/ }; do DEFS="$DEFS -DOIVAE_ABL_$t"; done
+/opt/rocm/bin/hipcc -O3 -fno-slp-vectorize -fPIC --offload-arch=gfx950 -std=c++17 $DEFS -c "$C/mfma_decoder.hip" -o "$HERE/tools/probe/abl_$TAGS.o"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$C/build/api.o" "$C/build/prox.o" "$C/build/generic.o" "$HERE/tools/probe/abl_$TAGS.o" \
+  "$C/build/mfma_encoder.o" "$C/build/flat_decoder.o" "$C/build/x3_encoder.o" "$C/build/noalloc.o" -o "$HERE/tools/probe/liboivae_abl_$TAGS.so"
+rm -f "$HERE/tools/probe/abl_$TAGS.o"
