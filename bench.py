@@ -27,19 +27,22 @@ G, DG, K, H, M = 1024, 64, 64, 64, 64
 GLOBAL_BATCH = 65536
 LR, WS_LR, LAM = 1e-3, 1e-4, 1.0
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
-BF16_MATRIX_PEAK_TFLOPS = 16 * 157.3  # dense bf16 = 16 x the fp32 matrix rate, same table
-# what the chip sustains on v_mfma_f32_32x32x16_bf16 alone with random operands (tools/probe/mfma_power.hip: the clock
-# falls from 2.37 to 1.79 GHz at the power limit; with all-zero operands the probe reaches 2445)
-BF16_MATRIX_SUSTAINED_TFLOPS = 1852.0
+F16_MATRIX_PEAK_TFLOPS = 16 * 157.3  # dense fp16/bf16 MFMA = 16 x the fp32 matrix rate, same table (2516.8)
+# what the chip sustains on v_mfma_f32_32x32x16_{bf16,f16} alone with random operands (tools/probe/mfma_power.hip: the
+# clock falls from 2.37 to 1.79 GHz at the power limit; with all-zero operands the probe reaches 2445)
+F16_MATRIX_SUSTAINED_TFLOPS = 1852.0
+PMC_FILE = os.path.join("profiles", "pmc_per_kernel_latest.json")
 
 
 def pmc_traffic():
-  """HBM bytes per decoder launch from the committed rocprofv3 PMC passes
-  (profiles/README.md); counters cannot be read from inside this process."""
+  """HBM bytes per decoder launch from the committed rocprofv3 PMC passes (profiles/README.md names the commit and
+  the commands); counters cannot be read from inside this process, so this is the newest committed measurement of
+  the same kernel, not this run's."""
   try:
-    d = json.load(open(os.path.join(ROOT, "profiles", "pmc_per_kernel_latest.json")))
-    k = next(v for n, v in sorted(d.items(), reverse=True) if "dec_x3" in n or "dec_mfma" in n)
-    return k["hbm_read_bytes_corrected"] + k["hbm_write_bytes"]
+    d = json.load(open(os.path.join(ROOT, PMC_FILE)))
+    name, k = next((n, v) for n, v in sorted(d.items(), reverse=True) if "dec_x3_64g" in n)
+    return {"bytes": k["hbm_read_bytes_corrected"] + k["hbm_write_bytes"], "read_bytes": k["hbm_read_bytes_corrected"],
+            "write_bytes": k["hbm_write_bytes"], "kernel": name, "source": PMC_FILE}
   except Exception:
     return None
 
@@ -56,8 +59,8 @@ def decoder_executed_flops(rows):
   return rows * G * 6 * 2 * 64 * 64 + G * 3 * 2 * 64 ** 3
 
 
-def decoder_bf16_flops(rows):
-  """16-bit matrix flops dec_x3_64h issues in the row loop: each of the six fp32 products (2 x 2 blocks of 32 x 32,
+def decoder_f16_flops(rows):
+  """16-bit matrix flops dec_x3_64g issues in the row loop: each of the six fp32 products (2 x 2 blocks of 32 x 32,
   four reduction steps of 16) as three fp16 products: 144 v_mfma_f32_32x32x16_f16 of 2*32*32*16 flops per 32-row
   tile and group."""
   return (rows + 31) // 32 * G * 144 * (2 * 32 * 32 * 16)
@@ -152,6 +155,8 @@ def main():
   ap.add_argument("--steps", type=int, default=10)
   ap.add_argument("--warmup", type=int, default=3)
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-extras", action="store_true", help="skip the comparator kernels, the range-change and the sustained run")
+  ap.add_argument("--sustain-seconds", type=float, default=10.0)
   args = ap.parse_args()
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,16 +175,24 @@ def main():
 
   rows = GLOBAL_BATCH // world
   eng, X = init_engine(device, rows, seed=100 + rank)
+  # two resident minibatches, alternated: a step never sees the X of the step before (the fp16 kernels keep
+  # max|X| of the previous pass in the workspace; same distribution, so the power of two does not move)
+  X2 = torch.rand(rows, G * DG, generator=torch.Generator(device=device).manual_seed(900 + rank), device=device)
+  batches = [X, X2]
   egen = torch.Generator(device=device).manual_seed(7 + rank)
   t_prox = WS_LR * LAM
-  dec_events = []
+  events = []
   sync = parallel.BucketedGradSync(eng) if world > 1 else None
+  counter = [0]
 
-  def step(timed):
+  def step(timed, xs=None):
+    xs = batches if xs is None else xs
+    Xs = xs[counter[0] % len(xs)]
+    counter[0] += 1
     eps = torch.randn(1, rows, K, generator=egen, device=device)
     if timed:
-      eng.trace = dec_events
-    eng.forward_backward(X, eps, 1.0, lam=LAM, grad_sync=sync)
+      eng.trace = events
+    eng.forward_backward(Xs, eps, 1.0, lam=LAM, grad_sync=sync)
     eng.trace = None
     if sync is not None:
       sync.wait()  # both gradient buckets averaged over ranks before Adam / SGD / prox
@@ -191,31 +204,66 @@ def main():
       torch.distributed.barrier()
     torch.cuda.synchronize()
 
+  def timed_steps(n, timed=True, xs=None):
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n):
+      step(timed, xs)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+      tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+      torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+      dt = float(tmax.item())
+    return dt
+
   for _ in range(args.warmup):
     step(False)
-  barrier()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    step(True)
-  barrier()
-  dt = time.perf_counter() - t0
-  if world > 1:
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax.item())
+  dt = timed_steps(args.steps)
+
+  extras = {}
+  if world == 1 and not args.no_extras:
+    # same-run comparators on full-width arithmetic (test hooks of the library, read on every call)
+    for tag, env in (("bf16x3_exact_operands", {"OIVAE_ENC": "bf16", "OIVAE_DEC": "p"}),
+                     ("fp32_matrix_instructions", {"OIVAE_ENC": "fp32", "OIVAE_DEC": "v4"})):
+      os.environ.update(env)
+      eng._ws_key = None
+      for _ in range(2):
+        step(False)
+      extras["ms_per_step_" + tag] = timed_steps(4, timed=False) / 4 * 1e3
+      for k in env:
+        os.environ.pop(k, None)
+    eng._ws_key = None
+    for _ in range(2):
+      step(False)
+    # worst case for the range guards: max|X| crosses a power of two every step, so every kernel that scales X
+    # (encoder forward, decoder, encoder backward) runs twice
+    X3 = X2 * 2.5
+    for _ in range(2):
+      step(False, [X, X3])
+    extras["ms_per_step_max_x_changes_every_step"] = timed_steps(6, timed=False, xs=[X, X3]) / 6 * 1e3
+    del X3
+    for _ in range(2):
+      step(False)
+    if args.sustain_seconds > 0:
+      n = max(args.steps, int(args.sustain_seconds / (dt / args.steps)) + 1)
+      ds = timed_steps(n, timed=False)
+      extras["sustained"] = {"steps": n, "seconds": ds, "ms_per_step": ds / n * 1e3, "samples_per_s": GLOBAL_BATCH * n / ds}
 
   if rank == 0:
     ms = dt / args.steps * 1e3
     value = GLOBAL_BATCH * args.steps / dt
-    dec_ms = [a.elapsed_time(b) for (name, a, b) in dec_events if name == "decoder"]
+    dec_ms = [a.elapsed_time(b) for (name, a, b) in events if name == "decoder"]
     dec_avg = sum(dec_ms) / max(1, len(dec_ms))
-    dec_flops = decoder_flops_per_row() * rows
-    achieved = dec_flops / (dec_avg * 1e-3) / 1e12 if dec_avg > 0 else 0.0
-    exe_flops = decoder_executed_flops(rows)
-    exe_rate = exe_flops / (dec_avg * 1e-3) / 1e12 if dec_avg > 0 else 0.0
+    sec = dec_avg * 1e-3
+    alg = decoder_flops_per_row() * rows
+    exe = decoder_executed_flops(rows)
+    f16 = decoder_f16_flops(rows)
+    tf = lambda fl: fl / sec / 1e12 if sec > 0 else 0.0
     per_kernel = {}
-    for name, a, b in dec_events:
+    for name, a, b in events:
       per_kernel.setdefault(name, []).append(a.elapsed_time(b))
+    traffic = pmc_traffic() if world == 1 else None
     out = {
       "metric": "oi-VAE train samples/sec (fwd+bwd+prox)", "value": value, "unit": "samples/s",
       "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -224,33 +272,41 @@ def main():
       "config": {"workload": "synthetic scale-up: G=1024 groups x 64 dims, K=64, H=M=64 two-layer generators, "
                              "global batch 65536, S=1", "global_batch": GLOBAL_BATCH,
                  "parallelism": "dp%d" % world, "rows_per_gpu": rows},
-      "roofline": {"bound": "mfma", "kernel": "dec_x3_64h (grouped decoder fwd+bwd)",
-                   "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                   "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic() if world == 1 else None,
-                   "avg_launch_ms": dec_avg, "flops_per_launch": dec_flops,
-                   "executed_flops_per_launch": exe_flops, "executed_tflops": exe_rate,
-                   "executed_frac": exe_rate / FP32_MATRIX_PEAK_TFLOPS,
-                   "bf16_flops_per_launch": decoder_bf16_flops(rows),
-                   "bf16_tflops": decoder_bf16_flops(rows) / (dec_avg * 1e-3) / 1e12 if dec_avg > 0 else 0.0,
-                   "bf16_peak": BF16_MATRIX_PEAK_TFLOPS,
-                   "bf16_frac": (decoder_bf16_flops(rows) / (dec_avg * 1e-3) / 1e12 / BF16_MATRIX_PEAK_TFLOPS) if dec_avg > 0 else 0.0,
-                   "bf16_sustained_peak": BF16_MATRIX_SUSTAINED_TFLOPS,
-                   "bf16_frac_of_sustained": (decoder_bf16_flops(rows) / (dec_avg * 1e-3) / 1e12 / BF16_MATRIX_SUSTAINED_TFLOPS) if dec_avg > 0 else 0.0,
-                   "note": "achieved/peak/frac: the reference algorithm's fp32 flops (9 products per group, SURVEY 8d) "
-                           "against the fp32 matrix peak, as in earlier rounds -- above 1 because the kernel composes "
-                           "Ws[g] with the generator's first Linear (6 products, executed_*) and issues each fp32 "
-                           "product as three fp16 matrix products of split, scaled operands (bf16_*: the 16-bit matrix "
-                           "instructions actually issued against the dense bf16 peak, bf16_sustained_peak: what the "
-                           "power-limited chip reaches on that instruction alone with random operands, "
-                           "tools/probe/mfma_power.hip; the kernel is bound by the vector issue port, DESIGN.md 3.0)"},
+      # the dominant kernel against the pipe it runs on: v_mfma_f32_32x32x16_f16
+      "roofline": {"bound": "mfma", "kernel": "dec_x3_64g (grouped decoder fwd+bwd, fp32 products as 3 fp16 MFMAs)",
+                   "achieved": tf(f16), "peak": F16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": tf(f16) / F16_MATRIX_PEAK_TFLOPS,
+                   "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
+                   "avg_launch_ms": dec_avg,
+                   "issued_f16_flops_per_launch": f16,
+                   "frac_of_sustained": tf(f16) / F16_MATRIX_SUSTAINED_TFLOPS, "sustained_peak": F16_MATRIX_SUSTAINED_TFLOPS,
+                   "algorithmic_flops_per_launch": alg, "algorithmic_tflops": tf(alg),
+                   "useful_frac": tf(alg) / F16_MATRIX_PEAK_TFLOPS,
+                   "fp32_equivalent": {"executed_flops_per_launch": exe, "executed_tflops": tf(exe),
+                                       "algorithmic_over_fp32_matrix_peak": tf(alg) / FP32_MATRIX_PEAK_TFLOPS,
+                                       "fp32_matrix_peak": FP32_MATRIX_PEAK_TFLOPS},
+                   "note": "achieved/frac: the 16-bit matrix flops the kernel ISSUES (144 v_mfma_f32_32x32x16_f16 per "
+                           "32-row tile and group) over the dense fp16 peak; useful_frac: the reference algorithm's fp32 "
+                           "flops (9 products per group, SURVEY 8d) over the same peak -- each fp32 product costs three "
+                           "fp16 products, and W^(g) z composed with the generator's first Linear makes 6 of the 9; "
+                           "frac_of_sustained: against what the power-limited chip reaches on that instruction alone "
+                           "with random operands; fp32_equivalent: the same work priced on the fp32 matrix pipe the "
+                           "kernel does not use (round 1's frac of 2.29).  avg_launch_ms is the decoder ENTRY POINT "
+                           "timed with HIP events on its stream: dec_x3_64g plus ~0.06 ms of helpers (max|z|, the "
+                           "image of z, the range guard and its gated second launch); profiles/ holds the "
+                           "rocprofv3 kernel trace of the same command.  The kernel is not matrix-bound: the chain "
+                           "wave's dependent sequence and the dz float atomics (8.6 GB per launch) bound it, DESIGN 3.0"},
       "step_model_tflops": (decoder_flops_per_row() + encoder_flops_per_row()) * GLOBAL_BATCH / (ms * 1e-3) / 1e12 / world,
       "entry_ms": {k: sum(v) / len(v) for k, v in per_kernel.items()},
+      "extra": extras,
       "arithmetic": "fp32 in, fp32 out, fp32 accumulation everywhere.  Encoder GEMMs and decoder products: two fp16 "
                     "terms per operand after an exact power-of-two scaling by the operand's maximum (or a bound of "
-                    "it), three v_mfma_f32_32x32x16_f16 products per fp32 product (x3_split.h; the all-bf16 kernels, "
-                    "three terms and six products, serve calls without a matching forward encoder call).  Error against float64 no larger "
-                    "than the fp32 matrix instructions' (tests/test_gpu_x3.py); OIVAE_ENC=bf16 selects the bf16 "
-                    "encoder kernels, OIVAE_ENC=fp32 OIVAE_DEC=v4 the fp32 matrix instructions",
+                    "it), three v_mfma_f32_32x32x16_f16 products per fp32 product (x3_split.h); every kernel that "
+                    "scales X checks the maximum it assumed against what it read and repeats itself otherwise.  "
+                    "Error against float64 no larger than the fp32 matrix instructions' (tests/test_gpu_x3.py).  "
+                    "extra.ms_per_step_bf16x3_exact_operands: OIVAE_ENC=bf16 OIVAE_DEC=p (operands carried exactly as "
+                    "three bf16 terms, six products); extra.ms_per_step_fp32_matrix_instructions: OIVAE_ENC=fp32 "
+                    "OIVAE_DEC=v4",
     }
     if world == 1:
       out["prox_roofline"] = prox_roofline(device)

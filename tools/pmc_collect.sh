@@ -10,7 +10,7 @@ ROOT=$(pwd)
 mkdir -p "$OUT"
 cd /tmp
 export TMPDIR=/tmp
-ARGS="$ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+ARGS="$ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$ROOT/$OUT/fetch" -- python3 $ARGS > "$ROOT/$OUT/fetch.log" 2>&1
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$ROOT/$OUT/write" -- python3 $ARGS > "$ROOT/$OUT/write.log" 2>&1
 timeout -s KILL 240 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d "$ROOT/$OUT/sq" -- python3 $ARGS > "$ROOT/$OUT/sq.log" 2>&1
