@@ -14,7 +14,8 @@
  *     nonzero OIVAE_E_* code; oivae_last_error() gives the message (per thread).
  *   - no entry point allocates or frees device memory, except oivae_init, which
  *     uploads a 128 KiB constant table once per device (and resolves the address of
- *     the static scratch array of oivae_encoder_bwd_noalloc_f32).
+ *     the static scratch array of oivae_encoder_bwd_noalloc_f32 and maps one
+ *     host-visible error word).
  *   - row-major everywhere.  B = batch rows, S = Monte-Carlo samples,
  *     N = S*B decoder rows (sample-major: row n = s*B + b, lib/oivae.py:53),
  *     K = latent dim, G = groups, H = group input dim, M = generator hidden
@@ -85,12 +86,14 @@ const char* oivae_last_error(void);
 const char* oivae_version(void);
 
 /* Bytes of workspace the step entry points need for these shapes and N rows.
- * The three step entry points below are one step's sequence: encoder forward, decoder, encoder backward, on the same
- * X, B and workspace, from one host thread.  At the shapes served by the matrix-core kernels the forward call leaves
- * max|X| in the workspace (and keeps it for the next step's forward call); the decoder and backward calls use it to
- * scale their fp16 operands when they follow a forward call of the same X and B, and take the scaling-free bf16
- * kernels otherwise (INTEGRATION.md "Arithmetic and switches").  Results are the same to fp32
- * accuracy either way; passing the same workspace every step saves the forward kernel a second pass. */
+ * The three step entry points below are one step's sequence -- encoder forward, decoder, encoder backward -- but
+ * each is a function of its own arguments: the library keeps no memory of earlier calls.  At the shapes served by
+ * the fp16-term kernels the workspace carries max|X| of the last pass over X from call to call; a kernel that
+ * scales X by it records the maximum it reads itself and is repeated (a gated second launch) when the two powers
+ * of two differ, so a stale, zeroed or foreign workspace costs one more pass of that kernel, never a wrong result
+ * (tests/test_gpu_ranges.py).  Passing the same workspace every step avoids the repeats.
+ * A bounded wait inside the decoder kernels that runs out raises a host-visible error word: the NEXT step entry
+ * point called on that device returns OIVAE_E_HIP (the earlier step's results are invalid). */
 int64_t oivae_workspace_bytes(const oivae_shape_t* shape, int64_t B, int32_t S);
 
 /* ---- proximal step ------------------------------------------------------
@@ -147,7 +150,7 @@ int oivae_encoder_fwd_f32(const oivae_shape_t* shape, const oivae_tensors_t* par
  *   loglik partial sums of -0.5*LOG2PI - log sigma - 0.5*((x - mu)/sigma)^2
  * and the gradients of loss = -loglik/(S*B) w.r.t. gen_W1,gen_b1,gen_W2,gen_b2,
  * log_sigma, Ws (written to `grads`, complete: not accumulated) and w.r.t. z
- * (dz [S*B,K], overwritten).  Neither mu nor sigma [N,D] is materialised; X is
+ * (dz, S*B*K floats, overwritten; [S*B,K] or [K,S*B]: oivae_dz_layout below).  Neither mu nor sigma [N,D] is materialised; X is
  * indexed as X[n mod B] instead of being repeated (lib/oivae.py:54).
  * The encoder entries of `grads` are not touched. */
 int oivae_decoder_fwd_bwd_f32(const oivae_shape_t* shape, const oivae_tensors_t* params,
@@ -156,8 +159,18 @@ int oivae_decoder_fwd_bwd_f32(const oivae_shape_t* shape, const oivae_tensors_t*
                               float gen_sig_off, float* dz,
                               void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Layout of the dz buffer that oivae_decoder_fwd_bwd_f32 writes and oivae_encoder_bwd_f32 reads, for these
+ * shapes and N = S*B rows: 0 = [N, K] row-major (sample-major rows), 1 = TRANSPOSED [K, N] (the matrix-core
+ * decoders of the all-32 / all-64 generator shapes), negative = error.  Both entry points derive it the same way
+ * from (shape, B, S) and the OIVAE_FORCE_GENERIC test switch; a host that reads dz, or feeds its own, asks here.
+ * dz is summed over the groups with float atomics by every decoder kernel except the flat (many-small-groups)
+ * path, so it -- and the encoder gradients computed from it -- can differ in the last bits from run to run
+ * (within 1e-5 of the tensor's scale: tests/test_gpu_dp.py); all other gradients are bit-reproducible. */
+int oivae_dz_layout(const oivae_shape_t* shape, int64_t B, int32_t S);
+
 /* ---- encoder backward -----------------------------------------------------
  * Replaces the encoder half of loss.backward() (lib/oivae.py:75):
+ * (dz as the decoder call of the same shape, B and S left it: oivae_dz_layout)
  *   dmu_q = sum_s dz[s] + (mu_q - mu_p)/sig_p^2 / B
  *   dsig_q = sum_s dz[s]*eps[s] + (sig_q/sig_p^2 - 1/sig_q) / B
  *   da = dsig_q * c * ea

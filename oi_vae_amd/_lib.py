@@ -21,7 +21,7 @@ SYMBOLS = [
   "oivae_init", "oivae_last_error", "oivae_version", "oivae_workspace_bytes",
   "oivae_prox_f32", "oivae_sgd_prox_f32", "oivae_prox_cols_f32", "oivae_encoder_fwd_f32",
   "oivae_decoder_fwd_bwd_f32", "oivae_encoder_bwd_f32", "oivae_finalize_f32",
-  "oivae_adam_f32", "oivae_encoder_bwd_noalloc_f32",
+  "oivae_adam_f32", "oivae_encoder_bwd_noalloc_f32", "oivae_dz_layout",
 ]
 
 
@@ -66,6 +66,8 @@ def bind(path):
   L.oivae_version.restype = ctypes.c_char_p
   L.oivae_workspace_bytes.argtypes = [PS, c_i64, c_i32]
   L.oivae_workspace_bytes.restype = c_i64
+  L.oivae_dz_layout.argtypes = [PS, c_i64, c_i32]
+  L.oivae_dz_layout.restype = ctypes.c_int
   L.oivae_prox_f32.argtypes = [c_vp, c_i64, c_i32, c_f, c_vp, c_vp, c_vp]
   L.oivae_sgd_prox_f32.argtypes = [c_vp, c_vp, c_i64, c_i32, c_f, c_f, c_i32, c_vp, c_vp, c_vp]
   L.oivae_prox_cols_f32.argtypes = [c_vp, c_vp, c_i32, c_i32, c_i32, c_f, c_vp, c_vp, c_vp]

@@ -641,6 +641,11 @@ extern "C" int oivae_decoder_fwd_bwd_f32(const oivae_shape_t* shape, const oivae
   return OIVAE_OK;
 }
 
+extern "C" int oivae_dz_layout(const oivae_shape_t* shape, int64_t B, int32_t S) {
+  if (check_shape(shape) != OIVAE_OK || B < 1 || S < 1) return -1;
+  return plan_decoder(*shape, B * (int64_t)S).mfma ? 1 : 0;
+}
+
 extern "C" int oivae_encoder_bwd_f32(const oivae_shape_t* shape, const oivae_tensors_t* grads, const float* X,
                                      int64_t B, int32_t S, const float* eps, float c, const float* prior_mu,
                                      const float* prior_sigma, int32_t prior_rows, const float* mu_q,

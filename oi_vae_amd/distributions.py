@@ -42,41 +42,58 @@ class Normal(object):
 
 
 class Gamma(object):
-  """Gamma(shape, rate) observation model (lib/distributions.py:59-71).  The reference's
-  class has only `logprob`; `size` is added so that `_DistributionCat.logprob` can split
-  its argument (in the reference that call raises AttributeError for a Gamma member)."""
+  """Gamma(shape, rate) observation model for non-negative data (counterpart of
+  lib/distributions.py:59-71, which has `logprob` only).  `size` and `sample` are additions: without
+  `size` a Gamma member cannot be split off by `_DistributionCat.logprob` (in the reference that call
+  raises AttributeError)."""
 
   def __init__(self, shape, rate):
-    assert shape.size() == rate.size()
+    if shape.shape != rate.shape:
+      raise AssertionError("Gamma: shape and rate tensors differ in size")
     self.shape = shape
     self.rate = rate
 
   def size(self, *args, **kwargs):
     return self.shape.size(*args, **kwargs)
 
+  def _dist(self):
+    return torch.distributions.Gamma(self.shape, self.rate, validate_args=False)
+
+  def sample(self):
+    return self._dist().sample()
+
   def logprob(self, x):
-    return torch.sum(self.shape * torch.log(self.rate) - torch.lgamma(self.shape)
-                     + (self.shape - 1) * torch.log(x) - self.rate * x)
+    """Sum over all elements of log Gamma(x; shape, rate)."""
+    return self._dist().log_prob(x).sum()
 
 
 class _DistributionCat(object):
-  """Concatenation of arbitrary member distributions along `dim`
-  (lib/distributions.py:73-86): evaluation-side only, the training step's fused
-  kernels take Normal outputs."""
+  """Independent member distributions side by side along `dim` (counterpart of
+  lib/distributions.py:73-86): a sample is the members' samples concatenated, the log-probability of a
+  concatenated x the sum of the members' over their own slices.  Evaluation side only: the training
+  step's kernels take Normal outputs (DistributionCat below folds those into one Normal)."""
 
   def __init__(self, distributions, dim=-1):
-    self.distributions = distributions
+    self.distributions = list(distributions)
     self.dim = dim
+
+  def _widths(self):
+    return [d.size(self.dim) for d in self.distributions]
 
   def sample(self):
     return torch.cat([d.sample() for d in self.distributions], dim=self.dim)
 
   def logprob(self, x):
-    xs = torch.split(x, [d.size(self.dim) for d in self.distributions], dim=self.dim)
-    return sum(d.logprob(xx) for d, xx in zip(self.distributions, xs))
+    total = 0
+    for d, piece in zip(self.distributions, torch.split(x, self._widths(), dim=self.dim)):
+      total = total + d.logprob(piece)
+    return total
 
   def entropy(self):
-    return sum(d.entropy() for d in self.distributions)
+    total = 0
+    for d in self.distributions:
+      total = total + d.entropy()
+    return total
 
 
 def DistributionCat(distributions, dim=-1):

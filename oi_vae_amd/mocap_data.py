@@ -28,11 +28,9 @@ _NUM = re.compile(r"[+-]?(?:[0-9]+\.?[0-9]*|\.[0-9]+)(?:[eE][+-]?[0-9]+)?\Z")
 
 
 def subject_trial_path(subject, trial, datadir=DATADIR):
-  """Path of the .amc file of a trial of a subject (lib/mocap_data.py:41-53)."""
-  subject_str = '{:0>2d}'.format(subject)
-  trial_str = '{:0>2d}'.format(trial)
-  filename = '{}_{}.amc'.format(subject_str, trial_str)
-  return os.path.join(datadir, 'cmu_mocap', 'subjects', subject_str, filename)
+  """<datadir>/cmu_mocap/subjects/SS/SS_TT.amc, the layout the reference reads (lib/mocap_data.py:41-53)."""
+  ss, tt = "%02d" % subject, "%02d" % trial
+  return os.path.join(datadir, "cmu_mocap", "subjects", ss, "%s_%s.amc" % (ss, tt))
 
 
 def parse_amc_data(raw_contents):
@@ -68,26 +66,34 @@ def parse_amc_data(raw_contents):
 
 
 def amc_to_array(parsed_amc, joint_order):
-  """Parsed frames -> (joint_dims, list of per-frame channel lists in `joint_order`)
-  with the reference's consistency checks (lib/mocap_data.py:62-87)."""
-  assert [i for i, _ in parsed_amc] == list(range(1, len(parsed_amc) + 1))
-  joint_dims = {joint: len(parsed_amc[0][1][joint]) for joint in joint_order}
-  assert all([sorted(joint_order) == sorted(kvs.keys()) for _, kvs in parsed_amc])
-  assert all([len(vs) == joint_dims[k] for _, kvs in parsed_amc for k, vs in kvs.items()])
-  arr = [[val for jn in joint_order for val in kvs[jn]] for _, kvs in parsed_amc]
-  return joint_dims, arr
+  """Parsed frames -> (joint_dims {joint: channel count}, rows: one flat channel list per frame, joints in
+  `joint_order`).  Rejects (AssertionError, as the reference does, lib/mocap_data.py:62-87) frame ids that are
+  not 1, 2, 3, ..., frames whose joint set differs from `joint_order`, and joints whose channel count changes."""
+  wanted = sorted(joint_order)
+  first = parsed_amc[0][1]
+  joint_dims = {joint: len(first[joint]) for joint in joint_order}
+  rows = []
+  for expect_id, (frame_id, channels) in enumerate(parsed_amc, 1):
+    assert frame_id == expect_id, "amc: frame ids must count from 1 (got %d at position %d)" % (frame_id, expect_id)
+    assert sorted(channels) == wanted, "amc: frame %d holds other joints than joint_order" % frame_id
+    row = []
+    for joint in joint_order:
+      values = channels[joint]
+      assert len(values) == joint_dims[joint], "amc: frame %d: %s has %d channels" % (frame_id, joint, len(values))
+      row.extend(values)
+    rows.append(row)
+  return joint_dims, rows
 
 
 def load_mocap_trial(subject, trial, joint_order=None, datadir=DATADIR):
-  """Subject/trial -> (joint_order, joint_dims, channel "array"), root first
-  (lib/mocap_data.py:89-109)."""
-  path = subject_trial_path(subject, trial, datadir=datadir)
-  raw_contents = open(path, 'r').read()
-  parsed = parse_amc_data(raw_contents)
+  """One trial of one subject -> (joint_order, joint_dims, rows); without a given order: root first, then
+  the other joints as the first frame lists them (lib/mocap_data.py:89-109)."""
+  with open(subject_trial_path(subject, trial, datadir=datadir), "r") as f:
+    frames = parse_amc_data(f.read())
   if joint_order is None:
-    joint_order = ['root'] + [k for k in parsed[0][1].keys() if k != 'root']
-  joint_dims, arr = amc_to_array(parsed, joint_order)
-  return joint_order, joint_dims, arr
+    joint_order = ["root"] + [joint for joint in frames[0][1] if joint != "root"]
+  joint_dims, rows = amc_to_array(frames, joint_order)
+  return joint_order, joint_dims, rows
 
 
 def save_amc(filename, seq, joint_order, joint_dims):

@@ -16,19 +16,22 @@ from .distributions import DistributionCat, Normal
 
 
 class NormalNet(object):
+  """x -> Normal(mu_net(x), sigma_net(x)): the encoder and every group generator are one of these
+  (lib/models.py:10-26).  Plain container: `OIVAE` reads `mu_net` / `sigma_net` to recognise the model."""
+
   def __init__(self, mu_net, sigma_net):
-    self.mu_net = mu_net
-    self.sigma_net = sigma_net
+    self.mu_net, self.sigma_net = mu_net, sigma_net
 
   def __call__(self, x):
-    return Normal(self.mu_net(x), self.sigma_net(x))
+    return Normal(mu=self.mu_net(x), sigma=self.sigma_net(x))
 
   def parameters(self):
-    return itertools.chain(self.mu_net.parameters(), self.sigma_net.parameters())
+    for net in (self.mu_net, self.sigma_net):
+      yield from net.parameters()
 
   def cuda(self):
-    self.mu_net.cuda()
-    self.sigma_net.cuda()
+    for net in (self.mu_net, self.sigma_net):
+      net.cuda()
 
 
 class FirstLayerSparseDecoder(object):
@@ -56,19 +59,18 @@ class FirstLayerSparseDecoder(object):
     self.col_norms = None
 
   def __call__(self, z):
-    return torch.cat(
-      [gen(m(z)) for gen, m in zip(self.group_generators, self.latent_to_group_maps)],
-      dim=-1)
+    outs = [gen(to_group(z)) for to_group, gen in zip(self.latent_to_group_maps, self.group_generators)]
+    return torch.cat(outs, dim=-1)
 
   def parameters(self):
-    return itertools.chain(
-      *[gen.parameters() for gen in self.group_generators],
-      *[m.parameters() for m in self.latent_to_group_maps])
+    for gen in self.group_generators:
+      yield from gen.parameters()
+    for to_group in self.latent_to_group_maps:
+      yield from to_group.parameters()
 
   def group_lasso_penalty(self):
-    return sum([
-      torch.sum(torch.sqrt(torch.sum(torch.pow(m.weight, 2), dim=0)))
-      for m in self.latent_to_group_maps])
+    """Sum over maps and latent columns of the column's Euclidean norm."""
+    return sum(torch.linalg.vector_norm(to_group.weight, dim=0).sum() for to_group in self.latent_to_group_maps)
 
   def cuda(self):
     for gen in self.group_generators:
@@ -135,14 +137,18 @@ class BayesianGroupLassoGenerator(object):
     self._engine = None  # set by OIVAE when the model is adopted
 
   def __call__(self, z):
-    # inference-time path (plots, reconstructions); the training step never calls it
-    return DistributionCat([gen(z @ self.Ws[i]) for i, gen in enumerate(self.group_generators)], dim=-1)
+    # inference-time path (plots, reconstructions); the training step never calls it.  All groups' first maps
+    # in one batched product: h[g] = z Ws[g]
+    h = torch.einsum("nk,gkh->gnh", z, self.Ws)
+    return DistributionCat([gen(h[g]) for g, gen in enumerate(self.group_generators)], dim=-1)
 
   def group_generators_parameters(self):
-    return itertools.chain(*[gen.parameters() for gen in self.group_generators])
+    for gen in self.group_generators:
+      yield from gen.parameters()
 
   def parameters(self):
-    return itertools.chain(*[gen.parameters() for gen in self.group_generators], [self.Ws])
+    yield from self.group_generators_parameters()
+    yield self.Ws
 
   def proximal_step(self, t):
     """Block soft-threshold of every row Ws[g,k,:] in place (lib/models.py:106-111),
@@ -162,7 +168,8 @@ class BayesianGroupLassoGenerator(object):
                  "oivae_prox_f32")
 
   def group_lasso_penalty(self):
-    return torch.sum(torch.sqrt(torch.sum(torch.pow(self.Ws, 2), dim=2)))
+    """Sum over groups and latent rows of ||Ws[g,k,:]|| (evaluated by `oivae_finalize_f32` inside the step)."""
+    return torch.linalg.vector_norm(self.Ws, dim=2).sum()
 
   def connectivity(self):
     """[G, K] matrix of row norms ||Ws[g,k,:]|| -- the paper's latent-to-group

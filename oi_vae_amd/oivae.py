@@ -17,9 +17,15 @@ class NormalPriorTheta(object):
     self.sigma = sigma
 
   def logprob(self, module):
-    return sum(
-      Normal(torch.zeros_like(p), self.sigma * torch.ones_like(p)).logprob(p)
-      for gen in module.group_generators for p in gen.parameters())
+    """Sum over every parameter tensor of every group generator of log N(theta; 0, sigma): one
+    closed-form term per tensor, -n (0.5 LOG2PI + log sigma) - 0.5 sum(theta^2) / sigma^2."""
+    from .distributions import LOG2PI
+    total = 0
+    for gen in module.group_generators:
+      for theta in gen.parameters():
+        const = 0.5 * LOG2PI.to(theta.device) + torch.log(torch.as_tensor(float(self.sigma), device=theta.device))
+        total = total - theta.numel() * const - 0.5 * torch.sum((theta / self.sigma) ** 2)
+    return total
 
 
 class OIVAE(object):

@@ -17,11 +17,23 @@ class _EngineOptimizer(object):
       groups = [{"params": groups}]
     self.param_groups = []
     for g in groups:
+      extra = sorted(k for k in g if k != "params" and k not in defaults)
+      if extra:
+        # one fused kernel with one set of options: anything it would silently ignore is refused
+        raise ValueError("%s: unsupported per-group option(s) %s (supported: %s); use torch.optim for them"
+                         % (type(self).__name__, ", ".join(extra), ", ".join(sorted(defaults))))
       d = dict(defaults)
       d.update({k: v for k, v in g.items() if k != "params"})
       d["params"] = list(g["params"])
       self.param_groups.append(d)
     self._engine = None
+
+  def _uniform(self, key):
+    """The one value of an option across all param groups (read at step time: schedulers may change it)."""
+    vals = {(tuple(g[key]) if isinstance(g[key], (list, tuple)) else g[key]) for g in self.param_groups}
+    if len(vals) != 1:
+      raise ValueError("engine-native optimizers apply one %r to every param group, got %s" % (key, sorted(vals)))
+    return vals.pop()
 
   def zero_grad(self, set_to_none=True):
     for g in self.param_groups:
@@ -32,16 +44,16 @@ class _EngineOptimizer(object):
     self._engine = engine
 
   def _lr(self):
-    lrs = {g["lr"] for g in self.param_groups}
-    if len(lrs) != 1:
-      raise ValueError("engine-native optimizers need one learning rate across param groups")
-    return lrs.pop()
+    return self._uniform("lr")
 
 
 class Adam(_EngineOptimizer):
   """torch.optim.Adam with default options over every non-Ws parameter."""
 
-  def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+  def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+    if weight_decay != 0 or amsgrad:
+      raise ValueError("oi_vae_amd.optim.Adam is torch.optim.Adam with default options (weight_decay=0, "
+                       "amsgrad=False): the fused kernel implements nothing else")
     super().__init__(params, lr=lr, betas=betas, eps=eps)
 
   def covers(self, engine):
@@ -52,8 +64,7 @@ class Adam(_EngineOptimizer):
   def step(self):
     if self._engine is None:
       raise RuntimeError("oi_vae_amd.optim.Adam steps engine parameters: pass it to OIVAE(optimizers=[...])")
-    g0 = self.param_groups[0]
-    self._engine.adam_step(self._lr(), betas=g0["betas"], eps=g0["eps"])
+    self._engine.adam_step(self._lr(), betas=self._uniform("betas"), eps=self._uniform("eps"))
 
 
 class SGD(_EngineOptimizer):

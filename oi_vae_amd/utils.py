@@ -1,22 +1,35 @@
-"""`Lambda` and `KL_Normals` with the reference's interface
-(/root/reference/lib/utils.py:9-28)."""
+"""`Lambda` and `KL_Normals` under the reference's names (/root/reference/lib/utils.py:9-28).
+
+`Lambda` is the one class of that file the engine depends on: the scripts express
+the encoder's `exp(.) * stddev_multiple + 1e-3` head and each generator's constant
+`log_sigma` head as `Lambda` modules (bars_data_oivae.py:84-85,98-101), and
+`oi_vae_amd.adopt` recognises those heads by this type and probes their constants.
+`KL_Normals` is kept for scripts that call it directly; the training step computes
+the same sum inside `enc_fwd_epilogue` (csrc/generic.hip).
+"""
 import torch
 
 
-def KL_Normals(d0, d1):
-  assert d0.mu.size() == d1.mu.size()
-  sigma0_sqr = torch.pow(d0.sigma, 2)
-  sigma1_sqr = torch.pow(d1.sigma, 2)
-  return torch.sum(-0.5 + (sigma0_sqr + torch.pow(d0.mu - d1.mu, 2)) / (2 * sigma1_sqr)
-                   + torch.log(d1.sigma) - torch.log(d0.sigma))
-
-
 class Lambda(torch.nn.Module):
-  def __init__(self, func, extra_args=(), extra_kwargs={}):
-    super(Lambda, self).__init__()
+  """A function as a module: `forward(x)` = `func(x, *extra_args, **extra_kwargs)`.
+  `extra_args` stays a public attribute: the scripts reach a generator's `log_sigma`
+  through `gen.sigma_net.extra_args[0]` (bars_data_oivae.py:238)."""
+
+  def __init__(self, func, extra_args=(), extra_kwargs=None):
+    super().__init__()
     self.func = func
-    self.extra_args = extra_args
-    self.extra_kwargs = extra_kwargs
+    self.extra_args = tuple(extra_args)
+    self.extra_kwargs = dict(extra_kwargs or {})
 
   def forward(self, x):
     return self.func(x, *self.extra_args, **self.extra_kwargs)
+
+
+def KL_Normals(d0, d1):
+  """Sum over all elements of KL(N(mu0, sigma0) || N(mu1, sigma1)) for two diagonal Gaussians of
+  one shape (`.mu`, `.sigma`); lib/oivae.py:50 divides it by the batch size."""
+  if d0.mu.shape != d1.mu.shape:
+    raise AssertionError("KL_Normals: shapes differ: %s vs %s" % (tuple(d0.mu.shape), tuple(d1.mu.shape)))
+  var0, var1 = d0.sigma * d0.sigma, d1.sigma * d1.sigma
+  per_element = (var0 + (d0.mu - d1.mu) ** 2) / (2 * var1) + torch.log(d1.sigma / d0.sigma) - 0.5
+  return per_element.sum()
