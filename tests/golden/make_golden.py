@@ -109,9 +109,19 @@ def export_params(inference_net, gen, typ, grads=False):
   return out
 
 
-def run_config(name, spec, seed, steps, lr, Ws_lr, lam, prior_rows, sigma_theta=1.0, data="uniform"):
-  """steps: list of dicts(B=, S=, c=, t=)."""
+ONLY = set(sys.argv[1:])   # config names to (re)generate; none given = all
+
+
+def run_config(name, spec, seed, steps, lr, Ws_lr, lam, prior_rows, sigma_theta=1.0, data="uniform",
+               full_steps=None, prepare=None):
+  """steps: list of dicts(B=, S=, c=, t=).  full_steps: step indices whose gradients, post-step parameters and
+  pre-prox Ws are recorded (None: every step); scalars, inputs and the zero mask are recorded for every step.
+  prepare(inference_net, gen): harness-side preparation of the initial state (the state is the caller's)."""
+  if ONLY and name not in ONLY:
+    return
   inference_net, gen, holder = build(spec, seed)
+  if prepare is not None:
+    prepare(inference_net, gen)
   D, K = spec["D"], spec["K"]
   typ = spec["gen_type"]
   adam = torch.optim.Adam([
@@ -155,11 +165,12 @@ def run_config(name, spec, seed, steps, lr, Ws_lr, lam, prior_rows, sigma_theta=
       out[pre + k] = np.float32(info[k].detach().item())
     out[pre + "mu_q"] = info["q_z"].mu.detach().numpy().copy()
     out[pre + "sig_q"] = info["q_z"].sigma.detach().numpy().copy()
-    for k, v in export_params(inference_net, gen, typ, grads=True).items():
-      out[pre + "grad/" + k] = v
-    for k, v in export_params(inference_net, gen, typ).items():
-      out[pre + "post/" + k] = v
-    out[pre + "pre_prox_Ws"] = gen.pre_prox.numpy().copy()
+    if full_steps is None or i in full_steps:
+      for k, v in export_params(inference_net, gen, typ, grads=True).items():
+        out[pre + "grad/" + k] = v
+      for k, v in export_params(inference_net, gen, typ).items():
+        out[pre + "post/" + k] = v
+      out[pre + "pre_prox_Ws"] = gen.pre_prox.numpy().copy()
     out[pre + "zero_mask"] = (gen.Ws.data.abs().sum(dim=2) == 0).numpy().astype(np.uint8)
     print(name, "step", i, "elbo", float(info["elbo"]), "zero rows", int(out[pre + "zero_mask"].sum()),
           "of", out[pre + "zero_mask"].size)
@@ -260,7 +271,25 @@ def main():
              dict(D=256, K=32, H=8, M=0, gen_type="linear", group_dims=[4] * 64), seed=10,
              steps=[dict(B=16, S=1, c=1.0, t=2.7)] + [dict(B=16, S=1, c=1.0, t=0.3)] * 2,
              lr=1e-3, Ws_lr=1e-4, lam=1, prior_rows="1")
-  prox_vectors()
+  # All-64 two-layer shape (the fp16-term kernels' shape) driven into the states training produces: 30 steps with a
+  # threshold that kills rows all along (and a weak one at the end under which some revive), one group that is dead
+  # from the first step, weak rows scattered over a healthy group, lr three times the scale-up config's, the encoder's
+  # std head switched 0.1 -> 1 on the way, a ragged two-sample batch at the end.  (Ws_lr is small against t so that the
+  # threshold, not the gradient step, decides which rows live -- with Ws_lr = 1e-4 and this loss scale no row dies in
+  # 30 steps; and lr = 2e-2 makes the RUN diverge, every trajectory within 1e-7 of it included.)
+  def sparse_start(inference_net, gen):
+    with torch.no_grad():
+      gen.Ws[1] *= 0.18            # dies within the first steps
+      gen.Ws[3] *= 1e-3            # a1 of this group is tiny beside its partner's in the workgroup
+      gen.Ws[3, :40] = 0.0         # and most of its rows are already exactly zero
+      gen.Ws[0, ::3] *= 0.3        # scattered weak rows in a healthy group
+  run_config("c4_trained64",
+             dict(D=320, K=64, H=64, M=64, gen_type="mlp", group_dims=[64] * 5), seed=21,
+             steps=[dict(B=64, S=1, c=0.1, t=0.28)] * 10 + [dict(B=64, S=1, c=1.0, t=0.28)] * 16 +
+                   [dict(B=45, S=2, c=1.0, t=0.05)] * 4,
+             lr=3e-3, Ws_lr=1e-6, lam=1, prior_rows="1", full_steps={0, 12, 29}, prepare=sparse_start)
+  if not ONLY or "prox_vectors" in ONLY:
+    prox_vectors()
 
 
 if __name__ == "__main__":

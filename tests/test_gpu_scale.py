@@ -240,3 +240,57 @@ def test_flat_many_small_groups_decoder_agrees_with_generic(tmp_path, typ, H, dg
       err = np.max(np.abs(ga - gb)) / max(np.max(np.abs(gb)), 1e-30)
       assert err < 2e-5, (name, err)
     off += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+
+
+def test_full_wide_prox_shape_whole_step():
+  """BASELINE.json configs[4] at its full size -- G = 8192 groups of 4 outputs, K = 256, H = 8, B = 1024, single-layer
+  generators -- through the whole step: the flat (GEMM-decomposed) decoder against the shape-generic kernels on the
+  same inputs (scalars 1e-5, gradients 2e-5 of scale), then Adam and the fused SGD + proximal step with the
+  threshold at the median row norm: about half of the 2 M rows die and the result equals the C oracle's on the
+  same pre-step bits, bit for bit."""
+  from oi_vae_amd import Engine, ModelSpec
+  from oracle import prox_oracle
+  G, dg, K, H, B = 8192, 4, 256, 8, 1024
+  eng = Engine(ModelSpec(D=G * dg, K=K, H=H, M=0, group_dims=[dg] * G, gen_type="linear"), device="cuda:0")
+  g = torch.Generator(device="cuda").manual_seed(12)
+  for n in ("enc_Wmu", "enc_bmu", "enc_Wsig", "enc_bsig", "gen_W2", "gen_b2"):
+    scale = 0.25 if n.startswith("gen") else 0.003
+    eng.p[n].copy_((torch.rand(eng.p[n].shape, generator=g, device="cuda") * 2 - 1) * scale)
+  eng.p["log_sigma"].fill_(float(np.log(1e-2)))
+  eng.p["Ws"].copy_(torch.randn(eng.p["Ws"].shape, generator=g, device="cuda"))
+  X = torch.rand(B, G * dg, generator=g, device="cuda")
+  eps = torch.randn(1, B, K, generator=g, device="cuda")
+  res = {}
+  try:
+    for mode in ("generic", "flat"):              # the library reads the switch on every call
+      if mode == "generic":
+        os.environ["OIVAE_FORCE_GENERIC"] = "1"
+      else:
+        os.environ.pop("OIVAE_FORCE_GENERIC", None)
+      eng._ws_key = None
+      out = eng.forward_backward(X, eps, 1.0)
+      torch.cuda.synchronize()
+      res[mode] = (eng.flat_grads.double().cpu().clone(), out["scalars"].double().cpu().clone())
+  finally:
+    os.environ.pop("OIVAE_FORCE_GENERIC", None)
+  a, b = res["flat"], res["generic"]
+  assert torch.isfinite(a[0]).all()
+  assert float(((a[1][:6] - b[1][:6]).abs() / b[1][:6].abs().clamp(min=1.0)).max()) < 1e-5
+  for name in eng.seg_off:
+    o, n = eng.seg_off[name], eng.seg_numel[name]
+    if n:
+      ga, gb = a[0][o:o + n], b[0][o:o + n]
+      assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-30, name
+  # optimizers + proximal step on the flat path's gradients
+  W0 = eng.p["Ws"].cpu().numpy().copy()
+  dW = eng.g["Ws"].cpu().numpy().copy()
+  lr = 1e-4
+  t = float(torch.linalg.vector_norm(eng.p["Ws"], dim=2).median())
+  eng.adam_step(1e-3)
+  eng.sgd_prox_step(lr, t)
+  torch.cuda.synchronize()
+  pre = (W0.astype(np.float64) + np.float64(np.float32(-lr)) * dW.astype(np.float64)).astype(np.float32)
+  want, wmask, _ = prox_oracle.proximal_step(pre, t)
+  assert np.array_equal(eng.p["Ws"].cpu().numpy().view(np.uint32), want.view(np.uint32))
+  assert np.array_equal(eng.zero_mask.cpu().numpy(), wmask)
+  assert 0.3 < wmask.mean() < 0.7

@@ -64,6 +64,34 @@ def test_oracle_tracks_reference(name):
     assert np.array_equal(info["zero_mask"], z[pre + "zero_mask"]), (name, i)
 
 
+def test_oracle_tracks_reference_through_a_sparse_trained_run():
+  """c4_trained64: 30 steps at the all-64 shape in which rows and whole groups die, revive and the generator and
+  log_sigma move far from their initial values (tests/golden/make_golden.py).  Gradients, post-step parameters and
+  pre-prox Ws are recorded at steps 0, 12 and 29 only; scalars and the zero set at every step."""
+  torch.set_num_threads(1)
+  z, spec = load("c4_trained64")
+  tr = O.OracleTrainer(spec, params_at(z, spec, "init/"), lr=spec["lr"], Ws_lr=spec["Ws_lr"],
+                       lam=spec["lam"], sigma_theta=spec["sigma_theta"])
+  dead_seen = 0
+  for i in range(spec["n_steps"]):
+    pre = "step%d/" % i
+    full = (pre + "post/Ws") in z.files
+    info = tr.step(z[pre + "X"], z[pre + "eps"], float(z[pre + "c"]), float(z[pre + "t"]), want_grads=full)
+    for k in ("z_kl", "loglik_term", "logprob_theta", "logprob_W", "loss", "elbo"):
+      want = float(z[pre + k])
+      assert abs(info[k] - want) <= 5e-6 * max(abs(want), 1.0), (i, k, info[k], want)
+    assert np.array_equal(info["zero_mask"], z[pre + "zero_mask"]), i
+    dead_seen = max(dead_seen, int(z[pre + "zero_mask"].sum()))
+    if full:
+      got_g = dict(flat_items(info["grads"]))
+      for k, b in flat_items(params_at(z, spec, pre + "grad/")):
+        assert rel_err(got_g[k], b) < 2e-5, (i, "grad", k, rel_err(got_g[k], b))
+      got_p = dict(flat_items(tr.model.export()))
+      for k, b in flat_items(params_at(z, spec, pre + "post/")):
+        assert rel_err(got_p[k], b) < 1e-5, (i, "param", k, rel_err(got_p[k], b))
+  assert dead_seen >= 140 and z["step1/zero_mask"][3].all()      # the fixture is what it claims to be
+
+
 def test_column_prox_oracle_matches_reference_bits():
   """FirstLayerSparseDecoder.proximal_step (lib/models.py:65-71): the oracle's column-sum order, MKL root and
   two-rounding scale against 228 cases recorded from the reference (tests/golden/make_golden_fls.py)."""
