@@ -191,7 +191,8 @@ int oivae_encoder_bwd_f32(const oivae_shape_t* shape, const oivae_tensors_t* gra
  * lives in a static device array of OIVAE_NOALLOC_SCRATCH_BYTES that each GPU holds from oivae_init until the
  * process ends.  Calls whose scratch would exceed it return OIVAE_E_WORKSPACE (need = 8*B*K bytes for dpre
  * + 16*K*min(256, ceil(B/64)) for the partials + 192*ceil(2K/128)*128*ceil(B/32) for the image when
- * 2K % 128 == 0, D % 128 == 0 and B % 32 == 0; e.g. K=64: B <= 8192).  Calls no hipMalloc/hipFree or any
+ * 2K % 128 == 0, D % 128 == 0 and B % 32 == 0, else up to 16 partial images of 8*K*D bytes when the fp32
+ * matrix-core kernel slices the batch; e.g. K=64: B <= 8192).  Calls no hipMalloc/hipFree or any
  * allocating routine; oivae_init(device) must have run.  Every call on a GPU shares that GPU's array: calls
  * that overlap on one GPU (two streams or threads) race; calls ordered on one stream do not. */
 #define OIVAE_NOALLOC_SCRATCH_BYTES (16u << 20)

@@ -120,6 +120,7 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
   w->flat = reinterpret_cast<float*>(take(plan.flat ? sizeof(float) * flat_decoder_floats(s, N, nullptr) : 0));
   w->x3_img = reinterpret_cast<uint32_t*>(take(x3_encoder_ws_bytes(s, B)));
   w->ranges = reinterpret_cast<uint32_t*>(take(256));
+  w->enc_bwd_part = reinterpret_cast<float*>(take(enc_bwd_part_bytes(s, B, x3_encoder_bwd_applies(s, B))));
   w->x3_z = reinterpret_cast<uint32_t*>(take((plan.mfma && s.K == 64) ? ((N + 31) / 32) * 24 * 1024 : 0));
   w->total_bytes = off;
   if (p && bytes < off)

@@ -55,6 +55,7 @@ struct Workspace {
   uint32_t* x3_z;                          // x3 decoder: split image of z, 24 KB per 32 rows
   uint32_t* x3_img;                        // x3 encoder: split image of the weights (fwd) / of dpre (bwd)
   uint32_t* ranges;                        // 64 words: operand maxima of the fp16 kernels (x3_encoder.hip "ranges")
+  float*  enc_bwd_part;                    // fp32 matrix-core encoder backward: [slices][2K][D] partial images (few-tile shapes)
   int64_t total_bytes;
 };
 
@@ -92,6 +93,7 @@ struct DecPlan {
   int64_t lds_bytes;
   bool mfma;        // fast path applies
   bool flat;        // many-small-groups path applies
+  bool single;      // single-layer generators with a skinny H: dec_single (generic.hip)
 };
 
 DecPlan plan_decoder(const oivae_shape_t& s, int64_t N);
@@ -105,6 +107,11 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
                     Workspace* out);
 int check_shape(const oivae_shape_t* s);
 int mfma_encoder_fwd_splits(const oivae_shape_t& s, int64_t B);  // mfma_encoder.hip
+int mfma_encoder_bwd_splits(const oivae_shape_t& s, int64_t B);  // mfma_encoder.hip: batch slices of the backward GEMM
+inline int64_t enc_bwd_part_bytes(const oivae_shape_t& s, int64_t B, bool x3_bwd) {
+  const int sp = x3_bwd ? 1 : mfma_encoder_bwd_splits(s, B);
+  return sp > 1 ? (int64_t)sizeof(float) * sp * 2 * s.K * s.D : 0;
+}
 // x3_encoder.hip: fp32 GEMMs as six bf16 matrix products
 bool x3_encoder_applies(const oivae_shape_t& s);
 int64_t x3_encoder_ws_bytes(const oivae_shape_t& s, int64_t B);
@@ -120,11 +127,13 @@ int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params,
 int encoder_bwd_run(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X, int64_t B, int32_t S,
                     const float* eps, float c, const float* prior_mu, const float* prior_sigma, int32_t prior_rows,
                     const float* mu_q, const float* sig_q, const float* ea, const float* dz, float* dpre,
-                    double* bias_part, int n_bias, uint32_t* x3_img, uint32_t* rng, hipStream_t st);
+                    double* bias_part, int n_bias, uint32_t* x3_img, uint32_t* rng, float* bwd_part, hipStream_t st);
 inline int enc_bias_blocks(int64_t B) { const int64_t bb = (B + 63) / 64; return (int)(bb > kBiasBlocks ? kBiasBlocks : bb); }
 // noalloc.hip: resolves the device address of the static scratch array for `device` (which must be current)
 int noalloc_scratch_setup(int device);
-void launch_slab_reduce(const float* slab, int64_t P, int chunks, float* dst, int64_t seg_off, int64_t seg_n,
-                        unsigned blocks, hipStream_t st);
+// decoder gradient partials [chunks][DecLayout::total] -> the six gradient tensors, summed in chunk order (one launch)
+struct SlabSegs { float* dst[6]; int64_t off[6], n[6]; };
+int launch_slab_reduce(const float* slab, const DecLayout& L, int chunks, const oivae_tensors_t* grads, hipStream_t st);
+void launch_partial_sum(const float* parts, int64_t P, int64_t n, int chunks, float* dst, hipStream_t st);
 
 }  // namespace oivae

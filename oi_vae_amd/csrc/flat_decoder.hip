@@ -234,9 +234,7 @@ int launch_decoder_flat(const oivae_shape_t& s, const oivae_tensors_t* params, c
   // dz[N, K] = dH Wk^T, reduction over G*H split into L.splits slices summed in index order
   if (L.splits > 1) {
     if (int rc = mfma_gemm_nt(Hc, N, GH, Wk, s.K, dzp, st)) return rc;
-    int64_t blocks = (N * s.K + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    launch_slab_reduce(dzp, N * s.K, L.splits, dz, 0, N * s.K, (unsigned)blocks, st);
+    launch_partial_sum(dzp, N * s.K, N * s.K, L.splits, dz, st);
     OIVAE_LAUNCH_CHECK();
   } else {
     if (int rc = mfma_gemm_nt(Hc, N, GH, Wk, s.K, dz, st)) return rc;

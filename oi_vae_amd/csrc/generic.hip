@@ -8,7 +8,12 @@
 // only dz, summed over groups with float atomics, is not.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace oivae {
+
+int64_t single_decoder_lds_bytes(const oivae_shape_t& s);
+bool single_decoder_applies(const oivae_shape_t& s);
 
 // ------------------------------------------------------------------------------
 // block reduction helper (double), result valid in thread 0
@@ -322,9 +327,209 @@ __global__ __launch_bounds__(256) void dec_generic(DecArgs a) {
   if (tid == 0) a.ll_part[(int64_t)chunk * gridDim.x + g] = tot;
 }
 
-// grads[i] = sum_c slab[c][i], c in index order
-__global__ __launch_bounds__(256) void slab_reduce(const float* __restrict__ slab, int64_t P, int chunks,
-                                                   float* __restrict__ dst, int64_t seg_off, int64_t seg_n) {
+// ------------------------------------------------------------------------------
+// Single-layer generators, mu_net = Linear(H, D_g) or Tanh -> Linear(H, D_g) with a skinny H (the reference's own
+// scripts: H = 1 for bars and MEG, bars_data_oivae.py:96-97, meg_oi_vae.py:178; H = 8 for mocap,
+// mo_mo_mocap_oivae.py:203-207), any K, ragged D_g.  With H this small there is no matrix to multiply: per group
+// the decoder is a rank-H update of a [rows, D_g] slab of X, HBM-bound on reading X once.  dec_generic spends its
+// time in phases that only R*H or D_g*H threads can share (and in 64-bit index arithmetic per element); here every
+// phase keeps all 256 threads busy by giving a thread a COLUMN when the sum runs over rows and a ROW when it runs
+// over columns, with one [64][65] LDS tile of dL/dmu between the two:
+//   phase 1, thread = (column dd, row quarter): x loaded coalesced, mu, log-likelihood, gm = dL/dmu -> tile;
+//            db2, dlog_sigma and dW2[d][:] are sums over rows = private registers of the column's thread;
+//   phase 2, thread = (row r, column quarter): dact[r][:] += gm[r][d] W2[d][:], private over all column chunks;
+//   then dh, dWs[g] = z^T dh (LDS accumulators over the workgroup's row tiles), dz += dh Ws[g]^T (float atomics).
+// Weight gradients are summed in a fixed order and written once per (group, row chunk): reproducible, as in dec_generic.
+// ------------------------------------------------------------------------------
+template <int H, bool TANH>
+__global__ __launch_bounds__(256) void dec_single(DecArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ double sred[256];
+  __shared__ int64_t sxrow[64];
+  constexpr int CP = H + 4;   // column parameters: W2[d][0..H), b2, 1/sigma, log sigma, d loss/d log_sigma coefficient
+  constexpr int CA = H + 2;   // column accumulators: dW2[d][0..H), db2, sum of 1 - q^2
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x, chunk = blockIdx.y, nchunks = gridDim.y;
+  const int K = a.K, KP = K | 1;
+  const int off = a.group_off[g];
+  const int Dg = a.group_off[g + 1] - off;
+  float* p = reinterpret_cast<float*>(smem_raw);
+  float* sWs = p;      p += K * H;
+  float* accWs = p;    p += K * H;
+  float* sz = p;       p += 64 * KP;
+  float* sact = p;     p += 64 * H;
+  float* sdh = p;      p += 64 * H;
+  float* sdap = p;     p += 4 * 64 * H;
+  float* tileg = p;    p += 64 * 65;
+  float* colpart = p;  p += 4 * 64 * CA;
+  float* colpar = p;   p += a.DC * CP;     // DC = the largest group's width here
+  float* colacc = p;
+
+  const float* Wsg = a.Ws + (int64_t)g * K * H;
+  for (int i = tid; i < K * H; i += 256) { sWs[i] = Wsg[i]; accWs[i] = 0.f; }
+  for (int d = tid; d < Dg; d += 256) {
+    const float e = expf(a.ls[off + d]);
+    const float sg = e + a.sig_off;
+#pragma unroll
+    for (int j = 0; j < H; ++j) colpar[d * CP + j] = a.W2[(int64_t)(off + d) * H + j];
+    colpar[d * CP + H] = a.b2[off + d];
+    colpar[d * CP + H + 1] = 1.0f / sg;
+    colpar[d * CP + H + 2] = logf(sg);
+    colpar[d * CP + H + 3] = e * a.inv / sg;
+#pragma unroll
+    for (int v = 0; v < CA; ++v) colacc[d * CA + v] = 0.f;
+  }
+  const int dd = tid & 63, rq = tid >> 6;   // phase 1: column of the chunk, quarter of the rows
+  const int r2 = tid & 63, cq = tid >> 6;   // phase 2: row, quarter of the chunk's columns
+  double ll_acc = 0.0;
+  const int64_t ntiles = (a.N + 63) / 64;
+  for (int64_t tile = chunk; tile < ntiles; tile += nchunks) {
+    const int64_t n0 = tile * 64;
+    __syncthreads();
+    for (int i = tid; i < 64 * K; i += 256) {
+      const int r = i / K, k = i - r * K;
+      const int64_t n = n0 + r;
+      sz[r * KP + k] = (n < a.N) ? a.z[n * K + k] : 0.f;
+    }
+    if (tid < 64) {
+      const int64_t n = n0 + tid;
+      sxrow[tid] = ((n < a.N ? n : a.N - 1) % a.B) * (int64_t)a.D + off;
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * H; i += 256) {
+      const int r = i / H, j = i % H;
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) acc = fmaf(sz[r * KP + k], sWs[k * H + j], acc);
+      sact[i] = TANH ? tanhf(acc) : acc;
+    }
+    float da[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) da[j] = 0.f;
+    float ll_tile = 0.f;
+    __syncthreads();
+    // x of this thread's column for its 16 rows, requested one column chunk ahead: the loads of chunk c0 + 64 fly
+    // while phase 2 of chunk c0 and the barriers run (issued one by one in front of their use, each cost an HBM round trip)
+    float xv[16];
+    auto load_x = [&](int c0) {
+      const int d = c0 + dd;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int row = 16 * rq + rr;
+        xv[rr] = (d < Dg && n0 + row < a.N) ? a.X[sxrow[row] + d] : 0.f;
+      }
+    };
+    load_x(0);
+    for (int c0 = 0; c0 < Dg; c0 += 64) {
+      // ---- phase 1: this thread's column over its 16 rows ----
+      const int d = c0 + dd;
+      const bool dvalid = d < Dg;
+      float w2r[H], accw[H], b2r = 0.f, isig = 0.f, lsig = 0.f, accb = 0.f, accs = 0.f;
+#pragma unroll
+      for (int j = 0; j < H; ++j) { w2r[j] = dvalid ? colpar[d * CP + j] : 0.f; accw[j] = 0.f; }
+      if (dvalid) { b2r = colpar[d * CP + H]; isig = colpar[d * CP + H + 1]; lsig = colpar[d * CP + H + 2]; }
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int row = 16 * rq + rr;
+        const bool live = dvalid && (n0 + row < a.N);
+        float gm = 0.f;
+        if (live) {
+          const float x = xv[rr];
+          float mu = b2r;
+#pragma unroll
+          for (int j = 0; j < H; ++j) mu = fmaf(sact[row * H + j], w2r[j], mu);
+          const float q = (x - mu) * isig;
+          ll_tile += -0.5f * kLog2Pi - lsig - 0.5f * q * q;
+          gm = -(q * isig) * a.inv;
+          accb += gm;
+          accs += 1.f - q * q;
+#pragma unroll
+          for (int j = 0; j < H; ++j) accw[j] = fmaf(gm, sact[row * H + j], accw[j]);
+        }
+        tileg[row * 65 + dd] = gm;
+      }
+      if (c0 + 64 < Dg) load_x(c0 + 64);
+#pragma unroll
+      for (int j = 0; j < H; ++j) colpart[(rq * 64 + dd) * CA + j] = accw[j];
+      colpart[(rq * 64 + dd) * CA + H] = accb;
+      colpart[(rq * 64 + dd) * CA + H + 1] = accs;
+      __syncthreads();
+      // ---- phase 2: this thread's row over its 16 columns; the four row quarters' column sums folded in order ----
+#pragma unroll 4
+      for (int q = 0; q < 16; ++q) {
+        const int c = 16 * cq + q;
+        if (c0 + c < Dg) {
+          const float gmv = tileg[r2 * 65 + c];
+#pragma unroll
+          for (int j = 0; j < H; ++j) da[j] = fmaf(gmv, colpar[(c0 + c) * CP + j], da[j]);
+        }
+      }
+      for (int i = tid; i < 64 * CA; i += 256) {
+        const int c = i / CA, v = i - c * CA;
+        if (c0 + c < Dg)
+          colacc[(c0 + c) * CA + v] += ((colpart[c * CA + v] + colpart[(64 + c) * CA + v]) + colpart[(128 + c) * CA + v]) +
+                                       colpart[(192 + c) * CA + v];
+      }
+      __syncthreads();
+    }
+    ll_acc += (double)ll_tile;
+    // ---- back through the activation; dWs and dz ----
+#pragma unroll
+    for (int j = 0; j < H; ++j) sdap[(cq * 64 + r2) * H + j] = da[j];
+    __syncthreads();
+    for (int i = tid; i < 64 * H; i += 256) {
+      const int r = i / H, j = i % H;
+      float v = ((sdap[(0 * 64 + r) * H + j] + sdap[(1 * 64 + r) * H + j]) + sdap[(2 * 64 + r) * H + j]) + sdap[(3 * 64 + r) * H + j];
+      if (TANH) { const float t = sact[i]; v *= 1.f - t * t; }
+      sdh[i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < K * H; i += 256) {
+      const int k = i / H, j = i % H;
+      float acc = 0.f;
+      for (int r = 0; r < 64; ++r) acc = fmaf(sz[r * KP + k], sdh[r * H + j], acc);
+      accWs[i] += acc;
+    }
+    for (int i = tid; i < 64 * K; i += 256) {
+      const int r = i / K, k = i - r * K;
+      const int64_t n = n0 + r;
+      if (n < a.N) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < H; ++j) acc = fmaf(sdh[r * H + j], sWs[k * H + j], acc);
+        atomicAdd(a.dz + n * K + k, acc);
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t cs = a.chunk_stride * chunk;
+  for (int d = tid; d < Dg; d += 256) {
+#pragma unroll
+    for (int j = 0; j < H; ++j) a.gW2[cs + (int64_t)(off + d) * H + j] = colacc[d * CA + j];
+    a.gb2[cs + off + d] = colacc[d * CA + H];
+    a.gls[cs + off + d] = colacc[d * CA + H + 1] * colpar[d * CP + H + 3];
+  }
+  for (int i = tid; i < K * H; i += 256) a.gWs[cs + (int64_t)g * K * H + i] = accWs[i];
+  const double tot = block_sum_double(ll_acc, sred);
+  if (tid == 0) a.ll_part[(int64_t)chunk * gridDim.x + g] = tot;
+}
+
+bool single_decoder_applies(const oivae_shape_t& s) {
+  if (getenv("OIVAE_FORCE_GENERIC")) return false;
+  if (s.gen_type == OIVAE_GEN_MLP) return false;
+  if (!(s.H == 1 || s.H == 2 || s.H == 4 || s.H == 8) || s.K > 128) return false;
+  return single_decoder_lds_bytes(s) <= 120 * 1024;
+}
+
+int64_t single_decoder_lds_bytes(const oivae_shape_t& s) {
+  const int64_t H = s.H, KP = s.K | 1;
+  return 4 * (2 * s.K * H + 64 * KP + 2 * 64 * H + 4 * 64 * H + 64 * 65 + 4 * 64 * (H + 2) + (int64_t)s.max_group_dim * (2 * H + 6));
+}
+
+// grads[i] = sum_c slab[c][i], c in index order; the six decoder parameter segments in one launch (blockIdx.y)
+__global__ __launch_bounds__(256) void slab_reduce(const float* __restrict__ slab, int64_t P, int chunks, SlabSegs sg) {
+  const int q = blockIdx.y;
+  float* __restrict__ dst = sg.dst[q];
+  const int64_t seg_off = sg.off[q], seg_n = sg.n[q];
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < seg_n; i += stride) {
@@ -334,10 +539,32 @@ __global__ __launch_bounds__(256) void slab_reduce(const float* __restrict__ sla
   }
 }
 
-void launch_slab_reduce(const float* slab, int64_t P, int chunks, float* dst, int64_t seg_off, int64_t seg_n,
-                        unsigned blocks, hipStream_t st) {
-  if (seg_n == 0) return;
-  hipLaunchKernelGGL(slab_reduce, dim3(blocks), dim3(256), 0, st, slab, P, chunks, dst, seg_off, seg_n);
+// dst[i] = sum_c parts[c * P + i], i < n, c in index order (one segment)
+void launch_partial_sum(const float* parts, int64_t P, int64_t n, int chunks, float* dst, hipStream_t st) {
+  if (n == 0) return;
+  SlabSegs sg = {};
+  sg.dst[0] = dst; sg.off[0] = 0; sg.n[0] = n;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(slab_reduce, dim3((unsigned)blocks, 1), dim3(256), 0, st, parts, P, chunks, sg);
+}
+
+int launch_slab_reduce(const float* slab, const DecLayout& L, int chunks, const oivae_tensors_t* grads, hipStream_t st) {
+  SlabSegs sg;
+  float* dst[6] = {grads->gen_W1, grads->gen_b1, grads->gen_W2, grads->gen_b2, grads->log_sigma, grads->Ws};
+  const int64_t off[7] = {L.oW1, L.ob1, L.oW2, L.ob2, L.oLs, L.oWs, L.total};
+  int64_t most = 0;
+  for (int q = 0; q < 6; ++q) {
+    sg.dst[q] = dst[q]; sg.off[q] = off[q]; sg.n[q] = off[q + 1] - off[q];
+    if (sg.n[q] != 0 && !dst[q]) return fail(OIVAE_E_ARG, "decoder: null gradient tensor %d", q);
+    if (sg.n[q] > most) most = sg.n[q];
+  }
+  int64_t blocks = (most + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(slab_reduce, dim3((unsigned)blocks, 6), dim3(256), 0, st, slab, L.total, chunks, sg);
+  OIVAE_LAUNCH_CHECK();
+  return OIVAE_OK;
 }
 
 // ------------------------------------------------------------------------------
@@ -489,12 +716,13 @@ bool mfma_encoder_applies(const oivae_shape_t& s);           // mfma_encoder.hip
 int launch_encoder_fwd_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, const float* X, int64_t B,
                             float* pre, hipStream_t st);
 int launch_encoder_bwd_mfma(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X,
-                            const float* dpre, int64_t B, hipStream_t st);
+                            const float* dpre, int64_t B, float* part, hipStream_t st);
 
 DecPlan plan_decoder(const oivae_shape_t& s, int64_t N) {
   DecPlan pl;
   pl.mfma = mfma_decoder_applies(s);
   pl.flat = !pl.mfma && flat_decoder_applies(s, N);
+  pl.single = !pl.mfma && !pl.flat && single_decoder_applies(s);
   pl.DC = s.max_group_dim < 64 ? s.max_group_dim : 64;
   pl.R = 0;
   pl.lds_bytes = 0;
@@ -512,6 +740,14 @@ DecPlan plan_decoder(const oivae_shape_t& s, int64_t N) {
   pl.chunks = (int32_t)c;
   if (pl.mfma) pl.chunks = mfma_decoder_chunks(s, N);
   if (pl.flat) pl.chunks = 1;
+  if (pl.single) {   // 64-row tiles; several workgroups per CU (their loads of X overlap) and at least one tile each
+    const int64_t t64 = (N + 63) / 64;
+    int64_t cc = (1536 + s.G - 1) / s.G;
+    if (cc > t64) cc = t64;
+    if (cc < 1) cc = 1;
+    if ((int64_t)s.G * cc > kMaxPartials) cc = kMaxPartials / s.G > 0 ? kMaxPartials / s.G : 1;
+    pl.chunks = (int32_t)cc;
+  }
   return pl;
 }
 
@@ -579,7 +815,7 @@ extern "C" int oivae_decoder_fwd_bwd_f32(const oivae_shape_t* shape, const oivae
   OIVAE_HIP_CHECK(hipMemsetAsync(dz, 0, sizeof(float) * N * s.K, st));
   if (pl.mfma) return launch_decoder_mfma(s, params, grads, X, B, S, z, gen_sig_off, dz, w, st);
   if (pl.flat) return launch_decoder_flat(s, params, grads, X, B, S, z, gen_sig_off, dz, w, st);
-  if (pl.R == 0)
+  if (pl.R == 0 && !pl.single)
     return fail(OIVAE_E_SHAPE, "oivae_decoder_fwd_bwd_f32: group weights do not fit LDS (K=%d H=%d M=%d)", s.K, s.H, s.M);
   const DecLayout L = dec_layout(s);
   const bool mlp = s.gen_type == OIVAE_GEN_MLP;
@@ -589,7 +825,8 @@ extern "C" int oivae_decoder_fwd_bwd_f32(const oivae_shape_t* shape, const oivae
   a.W1 = params->gen_W1; a.b1 = params->gen_b1; a.W2 = params->gen_W2; a.b2 = params->gen_b2;
   a.ls = params->log_sigma; a.Ws = params->Ws;
   if (pl.chunks > 1) {
-    OIVAE_HIP_CHECK(hipMemsetAsync(w.slab, 0, sizeof(float) * L.total * pl.chunks, st));
+    if (!pl.single)   // dec_generic accumulates into its destinations; dec_single writes each exactly once
+      OIVAE_HIP_CHECK(hipMemsetAsync(w.slab, 0, sizeof(float) * L.total * pl.chunks, st));
     a.gW1 = w.slab + L.oW1; a.gb1 = w.slab + L.ob1; a.gW2 = w.slab + L.oW2; a.gb2 = w.slab + L.ob2;
     a.gls = w.slab + L.oLs; a.gWs = w.slab + L.oWs;
     a.chunk_stride = L.total;
@@ -598,10 +835,12 @@ extern "C" int oivae_decoder_fwd_bwd_f32(const oivae_shape_t* shape, const oivae
       OIVAE_HIP_CHECK(hipMemsetAsync(grads->gen_W1, 0, sizeof(float) * (L.ob1 - L.oW1), st));
       OIVAE_HIP_CHECK(hipMemsetAsync(grads->gen_b1, 0, sizeof(float) * (L.oW2 - L.ob1), st));
     }
-    OIVAE_HIP_CHECK(hipMemsetAsync(grads->gen_W2, 0, sizeof(float) * (L.ob2 - L.oW2), st));
-    OIVAE_HIP_CHECK(hipMemsetAsync(grads->gen_b2, 0, sizeof(float) * (L.oLs - L.ob2), st));
-    OIVAE_HIP_CHECK(hipMemsetAsync(grads->log_sigma, 0, sizeof(float) * (L.oWs - L.oLs), st));
-    OIVAE_HIP_CHECK(hipMemsetAsync(grads->Ws, 0, sizeof(float) * (L.total - L.oWs), st));
+    if (!pl.single) {
+      OIVAE_HIP_CHECK(hipMemsetAsync(grads->gen_W2, 0, sizeof(float) * (L.ob2 - L.oW2), st));
+      OIVAE_HIP_CHECK(hipMemsetAsync(grads->gen_b2, 0, sizeof(float) * (L.oLs - L.ob2), st));
+      OIVAE_HIP_CHECK(hipMemsetAsync(grads->log_sigma, 0, sizeof(float) * (L.oWs - L.oLs), st));
+      OIVAE_HIP_CHECK(hipMemsetAsync(grads->Ws, 0, sizeof(float) * (L.total - L.oWs), st));
+    }
     a.gW1 = grads->gen_W1; a.gb1 = grads->gen_b1; a.gW2 = grads->gen_W2; a.gb2 = grads->gen_b2;
     a.gls = grads->log_sigma; a.gWs = grads->Ws;
     a.chunk_stride = 0;
@@ -612,6 +851,22 @@ extern "C" int oivae_decoder_fwd_bwd_f32(const oivae_shape_t* shape, const oivae
   a.DC = pl.DC;
   a.ll_part = w.ll_part;
   const dim3 grid((unsigned)s.G, (unsigned)pl.chunks);
+  if (pl.single) {
+    a.DC = s.max_group_dim;
+    const size_t lds = (size_t)single_decoder_lds_bytes(s);
+#define OIVAE_SINGLE_LAUNCH(HH, TT)                                                                       \
+  {                                                                                                      \
+    OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_single<HH, TT>),               \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+    hipLaunchKernelGGL((dec_single<HH, TT>), grid, dim3(256), lds, st, a);                                \
+  }
+    const bool th = s.gen_type == OIVAE_GEN_TANH_LINEAR;
+    if (s.H == 1) { if (th) OIVAE_SINGLE_LAUNCH(1, true) else OIVAE_SINGLE_LAUNCH(1, false) }
+    else if (s.H == 2) { if (th) OIVAE_SINGLE_LAUNCH(2, true) else OIVAE_SINGLE_LAUNCH(2, false) }
+    else if (s.H == 4) { if (th) OIVAE_SINGLE_LAUNCH(4, true) else OIVAE_SINGLE_LAUNCH(4, false) }
+    else { if (th) OIVAE_SINGLE_LAUNCH(8, true) else OIVAE_SINGLE_LAUNCH(8, false) }
+#undef OIVAE_SINGLE_LAUNCH
+  } else {
 #define OIVAE_DEC_LAUNCH(RR)                                                                             \
   {                                                                                                      \
     OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_generic<RR>),                  \
@@ -622,22 +877,10 @@ extern "C" int oivae_decoder_fwd_bwd_f32(const oivae_shape_t* shape, const oivae
   else if (pl.R == 32) OIVAE_DEC_LAUNCH(32)
   else OIVAE_DEC_LAUNCH(16)
 #undef OIVAE_DEC_LAUNCH
-  OIVAE_LAUNCH_CHECK();
-  if (pl.chunks > 1) {
-    struct Seg { float* dst; int64_t off, n; };
-    const Seg segs[6] = {{grads->gen_W1, L.oW1, L.ob1 - L.oW1}, {grads->gen_b1, L.ob1, L.oW2 - L.ob1},
-                         {grads->gen_W2, L.oW2, L.ob2 - L.oW2}, {grads->gen_b2, L.ob2, L.oLs - L.ob2},
-                         {grads->log_sigma, L.oLs, L.oWs - L.oLs}, {grads->Ws, L.oWs, L.total - L.oWs}};
-    for (int q = 0; q < 6; ++q) {
-      if (segs[q].n == 0) continue;
-      if (!segs[q].dst) return fail(OIVAE_E_ARG, "oivae_decoder_fwd_bwd_f32: null grad tensor %d", q);
-      int64_t blocks = (segs[q].n + 255) / 256;
-      if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(slab_reduce, dim3((unsigned)blocks), dim3(256), 0, st, w.slab, L.total, pl.chunks,
-                         segs[q].dst, segs[q].off, segs[q].n);
-      OIVAE_LAUNCH_CHECK();
-    }
   }
+  OIVAE_LAUNCH_CHECK();
+  if (pl.chunks > 1)
+    if (int rc = launch_slab_reduce(w.slab, L, pl.chunks, grads, st)) return rc;
   return OIVAE_OK;
 }
 
@@ -661,13 +904,13 @@ extern "C" int oivae_encoder_bwd_f32(const oivae_shape_t* shape, const oivae_ten
   Workspace w;
   if (int rc = carve_workspace(s, B, S, workspace, workspace_bytes, &w)) return rc;
   return encoder_bwd_run(s, grads, X, B, S, eps, c, prior_mu, prior_sigma, prior_rows, mu_q, sig_q, ea, dz, w.dpre,
-                         w.bias_part, w.n_bias, w.x3_img, w.ranges, (hipStream_t)stream);
+                         w.bias_part, w.n_bias, w.x3_img, w.ranges, w.enc_bwd_part, (hipStream_t)stream);
 }
 
 int oivae::encoder_bwd_run(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X, int64_t B, int32_t S,
                            const float* eps, float c, const float* prior_mu, const float* prior_sigma, int32_t prior_rows,
                            const float* mu_q, const float* sig_q, const float* ea, const float* dz, float* dpre,
-                           double* bias_part, int n_bias, uint32_t* x3_img, uint32_t* rng, hipStream_t st) {
+                           double* bias_part, int n_bias, uint32_t* x3_img, uint32_t* rng, float* bwd_part, hipStream_t st) {
   const bool dz_transposed = plan_decoder(s, B * (int64_t)S).mfma;
   const int64_t dz_sn = dz_transposed ? 1 : s.K, dz_sk = dz_transposed ? B * (int64_t)S : 1;
   const size_t pre_lds = sizeof(double) * (2 * (size_t)s.K + 512);
@@ -680,7 +923,7 @@ int oivae::encoder_bwd_run(const oivae_shape_t& s, const oivae_tensors_t* grads,
   if (x3_encoder_bwd_applies(s, B)) {
     if (int rc = launch_encoder_bwd_x3(s, grads, X, dpre, B, x3_img, rng, st)) return rc;
   } else if (mfma_encoder_applies(s)) {
-    if (int rc = launch_encoder_bwd_mfma(s, grads, X, dpre, B, st)) return rc;
+    if (int rc = launch_encoder_bwd_mfma(s, grads, X, dpre, B, bwd_part, st)) return rc;
   } else {
     const dim3 grid((unsigned)((s.D + 63) / 64), (unsigned)((2 * s.K + 31) / 32));
     hipLaunchKernelGGL(enc_bwd_wgrad_generic, grid, dim3(256), 0, st, X, dpre, B, s.D, s.K, grads->enc_Wmu,

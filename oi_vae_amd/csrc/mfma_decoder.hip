@@ -2387,18 +2387,8 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   } else if (s.K == 64) rc = launch_one<64, 64, 64, 64>(a, s.G, chunks, st);
   else rc = launch_one<32, 32, 32, 32>(a, s.G, chunks, st);
   if (rc) return rc;
-  if (chunks > 1) {
-    struct Seg { float* dst; int64_t off, n; };
-    const Seg segs[6] = {{grads->gen_W1, L.oW1, L.ob1 - L.oW1}, {grads->gen_b1, L.ob1, L.oW2 - L.ob1},
-                         {grads->gen_W2, L.oW2, L.ob2 - L.oW2}, {grads->gen_b2, L.ob2, L.oLs - L.ob2},
-                         {grads->log_sigma, L.oLs, L.oWs - L.oLs}, {grads->Ws, L.oWs, L.total - L.oWs}};
-    for (int q = 0; q < 6; ++q) {
-      int64_t blocks = (segs[q].n + 255) / 256;
-      if (blocks > 2048) blocks = 2048;
-      launch_slab_reduce(w.slab, L.total, chunks, segs[q].dst, segs[q].off, segs[q].n, (unsigned)blocks, st);
-    }
-    OIVAE_LAUNCH_CHECK();
-  }
+  if (chunks > 1)
+    if (int rc2 = launch_slab_reduce(w.slab, L, chunks, grads, st)) return rc2;
   return OIVAE_OK;
 }
 

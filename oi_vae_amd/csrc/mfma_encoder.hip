@@ -143,7 +143,11 @@ __global__ __launch_bounds__(256) void enc_fwd_gemm(const float* __restrict__ X,
 template <int TJ, int ND>
 __global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void enc_bwd_gemm(const float* __restrict__ X, const float* __restrict__ dpre,
                                                     int64_t B, int D, int K, float* __restrict__ dWmu,
-                                                    float* __restrict__ dWsig) {
+                                                    float* __restrict__ dWsig, int64_t tiles_per_split,
+                                                    int64_t split_stride) {
+  // gridDim.z > 1: the batch rows are cut into gridDim.z contiguous slices of tiles_per_split 32-row tiles and slice z
+  // writes its partial image at +z*split_stride floats (summed in slice order by the caller): shapes whose [2K, D]
+  // output has too few tiles to fill the chip (MEG-like: 2K = 20, D = 6600 -> 26 workgroups)
   // workgroup tile = (32*TJ) rows j x (128*ND) columns d; each wave owns all rows x 32*ND columns.
   // ND == 1 halves the LDS footprint so that two workgroups share a CU: one computes while the other
   // sits at its barrier or waits for its tile loads.
@@ -196,11 +200,15 @@ __global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void enc_bwd_gemm(const flo
 #pragma unroll
     for (int q = 0; q < ND; ++q) acc[i][q] = (f32x16)(0.f);
 
-  const int64_t T = (B + 31) / 32;
-  gload(0);
-  lstore(0);
+  const int64_t Tall = (B + 31) / 32;
+  const int64_t tbeg = (int64_t)blockIdx.z * tiles_per_split;
+  const int64_t T = (tbeg + tiles_per_split < Tall) ? tbeg + tiles_per_split : Tall;
+  dWmu += (int64_t)blockIdx.z * split_stride;
+  dWsig += (int64_t)blockIdx.z * split_stride;
+  gload(tbeg * 32);
+  lstore(tbeg & 1);
   __syncthreads();
-  for (int64_t t = 0; t < T; ++t) {
+  for (int64_t t = tbeg; t < T; ++t) {
     if (t + 1 < T) gload((t + 1) * 32);
     // Operands of k-step s+1 are read from LDS before the MFMAs of k-step s (two register sets), so the matrix
     // pipe never waits for an LDS round trip inside a tile.  Volatile LDS pointers keep the reads in this order
@@ -344,26 +352,51 @@ int launch_encoder_fwd_mfma(const oivae_shape_t& s, const oivae_tensors_t* param
 
 template <int TJ, int ND>
 static int launch_bwd(const float* X, const float* dpre, int64_t B, int D, int K, float* dWmu, float* dWsig,
-                      hipStream_t st) {
+                      hipStream_t st, int splits = 1, float* part = nullptr) {
   constexpr int BD = 128 * ND;
   const size_t lds = sizeof(float) * 2 * 32 * (BD + 32 * TJ);
   OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_gemm<TJ, ND>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const dim3 grid((unsigned)((D + BD - 1) / BD), (unsigned)((2 * K + 32 * TJ - 1) / (32 * TJ)));
-  hipLaunchKernelGGL((enc_bwd_gemm<TJ, ND>), grid, dim3(256), lds, st, X, dpre, B, D, K, dWmu, dWsig);
+  const int64_t T = (B + 31) / 32;
+  if (splits > 1 && part == nullptr) splits = 1;
+  const int64_t per = (T + splits - 1) / splits;
+  const int nz = (int)((T + per - 1) / per);   // every slice holds at least one tile
+  const dim3 grid((unsigned)((D + BD - 1) / BD), (unsigned)((2 * K + 32 * TJ - 1) / (32 * TJ)), (unsigned)nz);
+  const int64_t JD = (int64_t)2 * K * D;
+  if (nz > 1) {
+    hipLaunchKernelGGL((enc_bwd_gemm<TJ, ND>), grid, dim3(256), lds, st, X, dpre, B, D, K, part, part + (int64_t)K * D, per, JD);
+    OIVAE_LAUNCH_CHECK();
+    launch_partial_sum(part, JD, (int64_t)K * D, nz, dWmu, st);
+    launch_partial_sum(part + (int64_t)K * D, JD, (int64_t)K * D, nz, dWsig, st);
+  } else {
+    hipLaunchKernelGGL((enc_bwd_gemm<TJ, ND>), grid, dim3(256), lds, st, X, dpre, B, D, K, dWmu, dWsig, T, (int64_t)0);
+  }
   OIVAE_LAUNCH_CHECK();
   return OIVAE_OK;
 }
 
+// slices of the batch for the backward GEMM: only when its [2K, D] output has too few tiles for the chip
+int mfma_encoder_bwd_splits(const oivae_shape_t& s, int64_t B) {
+  if (!mfma_encoder_applies(s)) return 1;
+  const int J = 2 * s.K;
+  const int bj = (J % 128 == 0) ? 128 : ((J % 64 == 0) ? 64 : 32), bd = (J % 128 == 0) ? 128 : 256;
+  const int64_t wgs = (int64_t)((s.D + bd - 1) / bd) * ((J + bj - 1) / bj);
+  const int64_t T = (B + 31) / 32;
+  int splits = 1;
+  while (splits < 16 && wgs * splits < 256 && T / (splits * 2) >= 8) splits *= 2;
+  return splits;
+}
+
 int launch_encoder_bwd_mfma(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X,
-                            const float* dpre, int64_t B, hipStream_t st) {
+                            const float* dpre, int64_t B, float* part, hipStream_t st) {
   if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(dpre) & 15))
     return fail(OIVAE_E_ARG, "MFMA encoder: X and dpre must be 16-byte aligned");
   const int J = 2 * s.K;
+  const int splits = mfma_encoder_bwd_splits(s, B);
   // 128 x 128 tiles, two workgroups per CU: 8.84 ms against 8.98 ms for 128 x 256 at the scale-up shape
-  if (J % 128 == 0) return launch_bwd<4, 1>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st);
-  if (J % 64 == 0) return launch_bwd<2, 2>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st);
-  return launch_bwd<1, 2>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st);
+  if (J % 128 == 0) return launch_bwd<4, 1>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st, splits, part);
+  if (J % 64 == 0) return launch_bwd<2, 2>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st, splits, part);
+  return launch_bwd<1, 2>(X, dpre, B, s.D, s.K, grads->enc_Wmu, grads->enc_Wsig, st, splits, part);
 }
 
 // C[J, Dn] = P[M, J]^T * X[M, Dn] on the fp32 matrix cores, rows of M added in order (deterministic).

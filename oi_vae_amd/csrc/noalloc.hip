@@ -47,12 +47,13 @@ extern "C" int oivae_encoder_bwd_noalloc_f32(const oivae_shape_t* shape, const o
   OIVAE_HIP_CHECK(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDev || !g_scratch_ptr[dev])
     return fail(OIVAE_E_NOINIT, "oivae_encoder_bwd_noalloc_f32: oivae_init(%d) has not run", dev);
-  // carve: dpre | bias partials | image of dpre^T | ranges
+  // carve: dpre | bias partials | image of dpre^T | partial images of the fp32 backward GEMM | ranges
   const int n_bias = enc_bias_blocks(B);
   const int64_t b_dpre = align_up((int64_t)sizeof(float) * B * 2 * s.K, 256);
   const int64_t b_bias = align_up((int64_t)sizeof(double) * n_bias * 2 * s.K, 256);
   const int64_t b_img = align_up(x3_encoder_bwd_img_bytes(s, B), 256);
-  const int64_t need = b_dpre + b_bias + b_img + 256;
+  const int64_t b_part = align_up(enc_bwd_part_bytes(s, B, x3_encoder_bwd_applies(s, B)), 256);
+  const int64_t need = b_dpre + b_bias + b_img + b_part + 256;
   if (need > (int64_t)OIVAE_NOALLOC_SCRATCH_BYTES)
     return fail(OIVAE_E_WORKSPACE,
                 "oivae_encoder_bwd_noalloc_f32: B=%lld, K=%d need %lld bytes of scratch, the static array holds %lld; "
@@ -62,7 +63,8 @@ extern "C" int oivae_encoder_bwd_noalloc_f32(const oivae_shape_t* shape, const o
   float* dpre = reinterpret_cast<float*>(base);
   double* bias_part = reinterpret_cast<double*>(base + b_dpre);
   uint32_t* img = reinterpret_cast<uint32_t*>(base + b_dpre + b_bias);
-  uint32_t* rng = reinterpret_cast<uint32_t*>(base + b_dpre + b_bias + b_img);
+  float* part = reinterpret_cast<float*>(base + b_dpre + b_bias + b_img);
+  uint32_t* rng = reinterpret_cast<uint32_t*>(base + b_dpre + b_bias + b_img + b_part);
   return encoder_bwd_run(s, grads, X, B, S, eps, c, prior_mu, prior_sigma, prior_rows, mu_q, sig_q, ea, dz, dpre,
-                         bias_part, n_bias, img, rng, (hipStream_t)stream);
+                         bias_part, n_bias, img, rng, part, (hipStream_t)stream);
 }
