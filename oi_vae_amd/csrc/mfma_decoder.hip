@@ -54,7 +54,7 @@ struct MfmaDecArgs {
   float sig_off;
   double* ll_part;
   const uint32_t* zimg;  // dec_x3_64: split image of z (x3_split_z), else unused
-  const uint32_t* rng;   // dec_x3_64h/g: [0] max|X| the scales assume, [5] max|z|
+  const uint32_t* rng;   // dec_x3_64g: [0] max|X| the scales assume, [5] max|z|
   uint32_t* rng_seen;    // dec_x3_64g: max|x| of what the kernel read (atomicMax), or nullptr
   const uint32_t* gate;  // gated launch: returns at once when *gate == 0 (nullptr: always runs)
   uint32_t* err;         // the library's error word (host-mapped), raised by a timed-out LDS wait
@@ -981,7 +981,7 @@ __global__ __launch_bounds__(256) void x3_split_z(const float* __restrict__ z, i
       v[e] = z[n * 64 + 32 * kb + l31];
     }
   }
-  if (rng != nullptr) {   // dec_x3_64h: two fp16 terms of z * 2^e in fragments 2 grp, 2 grp + 1 (both orientations)
+  if (rng != nullptr) {   // dec_x3_64g: two fp16 terms of z * 2^e in fragments 2 grp, 2 grp + 1 (both orientations)
     float sz, iz;
     h2_scale_of(rng[5], &sz, &iz);
     const Frag2 f2 = split8_h2(v[0] * sz, v[1] * sz, v[2] * sz, v[3] * sz, v[4] * sz, v[5] * sz, v[6] * sz, v[7] * sz);
@@ -2315,12 +2315,11 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   a.zimg = nullptr;
   a.rng = nullptr;
   int rc;
-  // OIVAE_DEC=v1 (test hook) selects the layer-by-layer template kernel for the all-64 shape, which also serves
-  // launches whose dz image exceeds the 32-bit byte offsets of dec_mfma64_v4's atomics (N*K*4 >= 2^32)
   const char* dec_env = getenv("OIVAE_DEC");
-  // test hooks: OIVAE_DEC=v1 the layer-by-layer fp32 template kernel, OIVAE_DEC=v4 the fp32 composed-first-layer
-  // kernel, OIVAE_DEC=x3 the single-wave-per-SIMD split-bf16 kernel, OIVAE_DEC=p the all-bf16 pair; default for the
-  // all-64 shape: dec_x3_64h (dec_x3_64p without a matching forward encoder call)
+  // test hooks: OIVAE_DEC=v1 the layer-by-layer fp32 template kernel (which also serves launches whose dz image
+  // exceeds the 32-bit byte offsets of dec_mfma64_v4's atomics, N*K*4 >= 2^32), OIVAE_DEC=v4 the fp32
+  // composed-first-layer kernel, OIVAE_DEC=x3 the single-wave-per-SIMD split-bf16 kernel, OIVAE_DEC=p the all-bf16
+  // pair of waves, OIVAE_DEC=g (= unset) the default below
   const bool force_v1 = dec_env != nullptr && dec_env[0] == 'v' && dec_env[1] == '1';
   const bool use_x3 = (dec_env != nullptr && (dec_env[0] == 'x' || dec_env[0] == 'p')) ||
                       (dec_env == nullptr && N * (int64_t)s.K * 4 >= ((int64_t)1 << 32));

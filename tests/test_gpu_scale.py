@@ -64,7 +64,7 @@ def test_mfma_kernels_agree_with_generic_kernels(tmp_path):
     if mode == "onewave":
       env["OIVAE_DEC"] = "x3"   # the split-bf16 decoder with one wave per SIMD instead of the role-split pair
     if mode == "pair":
-      env["OIVAE_DEC"] = "p"    # the role-split pair with both waves on bf16 terms (default: chain wave on fp16 terms)
+      env["OIVAE_DEC"] = "p"    # the role-split pair with both waves on bf16 terms (default: dec_x3_64g, both waves on fp16 terms, two groups per workgroup)
     if mode == "bf16":
       env["OIVAE_ENC"] = "bf16"  # bf16 encoder kernels; the decoder then has no ranges and takes the all-bf16 pair
     out = tmp_path / (mode + ".npz")
@@ -294,3 +294,50 @@ def test_full_wide_prox_shape_whole_step():
   assert np.array_equal(eng.p["Ws"].cpu().numpy().view(np.uint32), want.view(np.uint32))
   assert np.array_equal(eng.zero_mask.cpu().numpy(), wmask)
   assert 0.3 < wmask.mean() < 0.7
+
+
+@pytest.mark.parametrize("typ,H,K", [("linear", 1, 10), ("tanh_linear", 8, 8), ("linear", 2, 16), ("tanh_linear", 4, 33),
+                                     ("tanh_linear", 1, 10)])
+def test_single_layer_decoder_agrees_with_generic(typ, H, K):
+  """dec_single (single-layer generators, skinny H: the bars / mocap / MEG scripts' own shapes) against dec_generic on
+  MEG-like ragged groups: widths from 1 to 300 (several 64-column chunks, partial chunks, one-column groups), a row
+  count that ends in a partial 64-row tile, three Monte-Carlo samples (rows of X repeat), odd K.  Scalars 1e-5,
+  gradients 2e-5 of scale; the weight gradients of dec_single must also be bit-reproducible run to run."""
+  from oi_vae_amd import Engine, ModelSpec
+  rng = np.random.default_rng(5)
+  dims = [1, 300, 64, 65, 7, 128, 129, 2, 63, 191] + rng.integers(20, 260, 12).tolist()
+  dims[-1] += (-sum(dims)) % 4
+  G, D, B, S = len(dims), sum(dims), 333, 3
+  eng = Engine(ModelSpec(D=D, K=K, H=H, M=0, group_dims=dims, gen_type=typ), device="cuda:0")
+  g = torch.Generator(device="cuda").manual_seed(9)
+  for n in ("enc_Wmu", "enc_bmu", "enc_Wsig", "enc_bsig", "gen_W2", "gen_b2"):
+    scale = 0.3 if n.startswith("gen") else 0.02
+    eng.p[n].copy_((torch.rand(eng.p[n].shape, generator=g, device="cuda") * 2 - 1) * scale)
+  eng.p["log_sigma"].copy_(torch.log(torch.rand(eng.p["log_sigma"].shape, generator=g, device="cuda") * 0.3 + 0.02))
+  eng.p["Ws"].copy_(0.4 * torch.randn(eng.p["Ws"].shape, generator=g, device="cuda"))
+  X = torch.rand(B, D, generator=g, device="cuda")
+  eps = torch.randn(S, B, K, generator=g, device="cuda")
+  res = {}
+  try:
+    for mode in ("generic", "single", "single_again"):
+      if mode == "generic":
+        os.environ["OIVAE_FORCE_GENERIC"] = "1"
+      else:
+        os.environ.pop("OIVAE_FORCE_GENERIC", None)
+      eng._ws_key = None
+      out = eng.forward_backward(X, eps, 0.8)
+      torch.cuda.synchronize()
+      res[mode] = (eng.flat_grads.double().cpu().clone(), out["scalars"].double().cpu().clone())
+  finally:
+    os.environ.pop("OIVAE_FORCE_GENERIC", None)
+  a, b = res["single"], res["generic"]
+  assert torch.isfinite(a[0]).all()
+  assert float(((a[1][:6] - b[1][:6]).abs() / b[1][:6].abs().clamp(min=1.0)).max()) < 1e-5
+  for name in eng.seg_off:
+    o, n = eng.seg_off[name], eng.seg_numel[name]
+    if n:
+      ga, gb = a[0][o:o + n], b[0][o:o + n]
+      assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-30, name
+  for name in ("gen_W2", "gen_b2", "log_sigma", "Ws"):     # fixed summation order: no float atomics behind these
+    o, n = eng.seg_off[name], eng.seg_numel[name]
+    assert torch.equal(res["single"][0][o:o + n], res["single_again"][0][o:o + n]), name

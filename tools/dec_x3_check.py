@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""dec_x3_64 (OIVAE_DEC=x3) and dec_x3_64p (OIVAE_DEC=p, the default) beside dec_mfma64_v4: agreement on a ragged small case, then time at the scale-up shape."""
+"""dec_x3_64 (OIVAE_DEC=x3), dec_x3_64p (OIVAE_DEC=p) and dec_x3_64g (OIVAE_DEC=g, the default) beside
+dec_mfma64_v4: agreement on a ragged small case, then time at the scale-up shape."""
 import os
 import sys
 
@@ -21,13 +22,13 @@ def agree():
   X = torch.rand(B, 24 * 64, generator=g, device="cuda")
   eps = torch.randn(S, B, 64, generator=g, device="cuda")
   res = {}
-  for m in ("v4", "x3", "p", "h"):
+  for m in ("v4", "x3", "p", "g"):
     setmode(m)
     out = eng.forward_backward(X, eps, 0.7)
     torch.cuda.synchronize()
     res[m] = (eng.flat_grads.clone(), out["scalars"].clone())
-  a, b = res[os.environ.get("CHECK_MODE", "h")], res["v4"]
-  print("scalars p: ", a[1][:6].tolist())
+  a, b = res[os.environ.get("CHECK_MODE", "g")], res["v4"]
+  print("scalars:   ", a[1][:6].tolist())
   print("scalars v4:", b[1][:6].tolist())
   for name in eng.seg_off:
     o, n = eng.seg_off[name], eng.seg_numel[name]
@@ -42,7 +43,7 @@ def timing():
   B = 65536
   X = torch.rand(B, 65536, generator=g, device="cuda")
   eps = torch.randn(1, B, 64, generator=g, device="cuda")
-  for m in ("x3", "p", "h", "p", "h"):
+  for m in ("x3", "p", "g", "p", "g"):
     setmode(m)
     eng.forward_backward(X, eps, 1.0)
     eng.trace = []

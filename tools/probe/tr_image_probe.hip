@@ -1,6 +1,6 @@
 // Probe: can the chain decoder's FORWARD weight image (lane = output row m, 8 slots = k in accumulator order, two
 // fp16 terms) also serve the backward product (lane = k, slots = m) through ds_read_b64_tr_b16?  Builds both images
-// of a random 64 x 64 matrix the way dec_x3_64h does and compares, for every (rb, ks, term), the backward fragment
+// of a random 64 x 64 matrix the way round 1's dec_x3_64h did and compares, for every (rb, ks, term), the backward fragment
 // read with one ds_read_b128 from the transposed image against two transposed reads from the forward image.
 //   hipcc -O3 --offload-arch=gfx950 tools/probe/tr_image_probe.hip -o tools/probe/tr_image_probe && tools/probe/tr_image_probe
 #include <hip/hip_runtime.h>
