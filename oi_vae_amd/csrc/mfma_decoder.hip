@@ -1290,7 +1290,10 @@ constexpr int kX3DecLdsP = kX3DecLds + 64;
 #endif
 __device__ __forceinline__ void lds_wait_ge(const volatile uint32_t* f, uint32_t v, volatile uint32_t* err) {
   int guard = 0;
-  while (__builtin_amdgcn_readfirstlane(*f) < v) {
+  // the counter lives in LDS: read it as such (through the generic pointer it is a flat load, which also waits for
+  // every global load in flight)
+  const volatile __attribute__((address_space(3))) uint32_t* fl = (const volatile __attribute__((address_space(3))) uint32_t*)f;
+  while (__builtin_amdgcn_readfirstlane(*fl) < v) {
     if (++guard >= OIVAE_TEST_WAIT_LIMIT) {
       if (err != nullptr && (threadIdx.x & 63) == 0) *err = 0x4c445357u;   // "LDSW"
       break;
@@ -1302,7 +1305,7 @@ __device__ __forceinline__ void lds_wait_ge(const volatile uint32_t* f, uint32_t
 __device__ __forceinline__ void lds_post(volatile uint32_t* f, uint32_t v) {
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's tile accesses are done
-  *f = v;
+  *(volatile __attribute__((address_space(3))) uint32_t*)f = v;
   __builtin_amdgcn_sched_barrier(0);   // or the scheduler sinks the store below the MFMAs that follow: the partner waits
 }
 
@@ -1682,11 +1685,23 @@ __device__ __forceinline__ x3_u32x2 lds_read_tr16(const char* p) {
       (__attribute__((address_space(3))) x3_s16x4*)(const_cast<char*>(p))));
 }
 
+// Scratch builds only (tools/build_ablation.sh TIMES, tools/dec_probe.py): wall-clock stamps of wave 0 of every
+// workgroup at the phase boundaries of dec_x3_64g, read back through oivae_probe_read.  (The stamps cost registers:
+// that build spills in the row loop, so only its set-up and end-of-kernel phases are representative.)
+#ifdef OIVAE_ABL_TIMES
+__device__ unsigned long long g_probe[8192 * 8];
+#define OIVAE_PROBE(i) \
+  do { if (threadIdx.x == 0) g_probe[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define OIVAE_PROBE(i) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
   constexpr int K = 64, H = 64, M = 64, DG = 64, LW = 65;
   constexpr float kC = 2.885390081777927f;  // 2*log2(e): tanh(x) = 1 - 2/(exp2(kC x) + 1)
   constexpr float kSt = 8192.0f;            // t lies in (-1, 1)
   if (a.gate != nullptr && *a.gate == 0) return;
+  OIVAE_PROBE(0);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint32_t* img = reinterpret_cast<uint32_t*>(smem_raw);
   float* vec = reinterpret_cast<float*>(img + kPairImg);
@@ -1796,7 +1811,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
     if (tid < 64) {
       sb1[tid] *= q1 * qz;    // accumulator initial values in the products' scaled units
       sb2[tid] *= q2 * kSt;
-      sC3[tid] *= qg;         // gmu is produced in its operand's scaled units
+      sC3[tid] *= -qg;        // gmu is produced in its operand's scaled units; the chain multiplies (x - mu) by - c3
     }
     {  // the three images in two fp16 terms: item = (row r, step ks, lane half h2) -> 8 slots -> two 16-byte terms
       const int r = tid >> 3, ks = (tid >> 1) & 3, h2 = tid & 1;
@@ -1816,8 +1831,10 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
           *reinterpret_cast<x3_u32x4*>(img + (q * 3 + w) * 4096 + ((((r >> 5) * 4 + ks) * 2 + p) * 64 + h2 * 32 + (r & 31)) * 4) = f.p[p];
       }
     }
+    OIVAE_PROBE(1 + q);
   }
   __syncthreads();
+  OIVAE_PROBE(3);
   auto wfrag = [&](const uint32_t* imgl, int which, int rb, int ks) {
     Frag2 f;
 #pragma unroll
@@ -1841,7 +1858,13 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
     return f;
   };
   auto afrag2n = [&](const f32x16& v, int q) {   // values already in scaled units
+#ifdef OIVAE_ABL_NOCSPLIT   // timing only: the splits replaced by one bit operation per pair
+    Frag2 f;
+    for (int e = 0; e < 4; ++e) { f.p[0][e] = __float_as_uint(v[8 * q + e]) & 0x3bff3bffu; f.p[1][e] = __float_as_uint(v[8 * q + 4 + e]) & 0x3bff3bffu; }
+    return f;
+#else
     return split8_h2(v[8 * q], v[8 * q + 1], v[8 * q + 2], v[8 * q + 3], v[8 * q + 4], v[8 * q + 5], v[8 * q + 6], v[8 * q + 7]);
+#endif
   };
   // One chained product, both 32-row output blocks, as eight pinned units (u = 4 rb + ks) of three MFMAs: the weight
   // fragments of unit u+2 are requested and the operand of step u+1 is split inside unit u's region (dec_x3_64p).
@@ -1856,10 +1879,44 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
       if (u + 2 < 8) w[(u + 2) % 3] = wf((u + 2) >> 2, (u + 2) & 3);
       if (u + 1 < 4) bf[u + 1] = make(u + 1);
       side(u);
+#ifdef OIVAE_ABL_NOCMFMA   // timing only: the chain wave without its matrix instructions
+      acc[u >> 2][u & 15] += __uint_as_float((w[u % 3].p[0][0] ^ bf[u & 3].p[1][0] ^ w[u % 3].p[1][3] ^ bf[u & 3].p[0][3]) & 0x3fffffffu);
+#else
       h2mm(acc[u >> 2], w[u % 3], bf[u & 3]);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+#ifdef OIVAE_ABL_CHAIN2
+  // variant: the two accumulators of a product alternate, so that consecutive matrix instructions are independent
+  auto chain_mm2 = [&](f32x16* acc, auto&& wf, Frag2* bf, auto&& make, auto&& side) {
+    Frag2 w[2][2];
+    w[0][0] = wf(0, 0);
+    w[0][1] = wf(1, 0);
+    bf[0] = make(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks + 1 < 4) {
+        w[(ks + 1) & 1][0] = wf(0, ks + 1);
+        w[(ks + 1) & 1][1] = wf(1, ks + 1);
+        bf[ks + 1] = make(ks + 1);
+      }
+      const Frag2& a0 = w[ks & 1][0];
+      const Frag2& a1 = w[ks & 1][1];
+      acc[0] = mfma_f16(a0.p[1], bf[ks].p[0], acc[0]);
+      acc[1] = mfma_f16(a1.p[1], bf[ks].p[0], acc[1]);
+      acc[0] = mfma_f16(a0.p[0], bf[ks].p[1], acc[0]);
+      acc[1] = mfma_f16(a1.p[0], bf[ks].p[1], acc[1]);
+      acc[0] = mfma_f16(a0.p[0], bf[ks].p[0], acc[0]);
+      acc[1] = mfma_f16(a1.p[0], bf[ks].p[0], acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int u = 4; u < 8; ++u) side(u);
+  };
+#define chain_mm chain_mm2
+#endif
   auto init_t = [&](f32x16& acc, const float* v0, int rb) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1914,7 +1971,12 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
       const int r0 = tile * 32;
       const int nT = (r0 + l31 < N32) ? r0 + l31 : N32 - 1;
       const float liveT = (r0 + l31 < N32) ? 1.0f : 0.0f;
+      const bool partial = r0 + 32 > N32;
+#ifdef OIVAE_ABL_NOX    // timing only: every tile reads the same rows of X (L2 hits)
+      const float* xrow = a.X + (int64_t)l31 * (int64_t)a.D + 4 * hh;
+#else
       const float* xrow = a.X + (one_sample ? (int64_t)nT : (int64_t)nT % a.B) * (int64_t)a.D + 4 * hh;
+#endif
       f32x16 dz[2];
       dz[0] = (f32x16)(0.f);
       dz[1] = (f32x16)(0.f);
@@ -1926,7 +1988,8 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
         const float* sb1 = vec + 192 * q;
         const float* sb2 = sb1 + 64;
         const float* sC3 = sb2 + 64;
-        const float k_inv1 = q ? inv1[1] : inv1[0], k_inv2 = q ? inv2[1] : inv2[0], k_omtC = q ? omtC[1] : omtC[0];
+        const float k_inv1 = q ? inv1[1] : inv1[0], k_ninv2 = -(q ? inv2[1] : inv2[0]), k_omtC = q ? omtC[1] : omtC[0];
+        const float k_nomt2 = -(k_omtC / (kSt * kSt));
         const float* xT = xrow + (int64_t)(2 * pairIdx + q) * DG;
         f32x4 xq[2][4];
 #pragma unroll
@@ -1940,43 +2003,69 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
         auto none = [&](int) {};
         chain_mm(uT, [&](int rb, int ks) { return wfrag(imgl, 0, rb, ks); }, zf, [&](int ks) { return zf[ks]; }, none);
         // ---- t = tanh: published first, split during the next product ----
+        // (whole-vector expressions: the compiler turns them into packed fp32 instructions, two elements each)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < 2; ++rb) {
+#ifdef OIVAE_ABL_NOTANH
+          uT[rb] = uT[rb] * k_inv1 + kSt;
+#else
+          f32x16 e = uT[rb] * k_inv1;
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            uT[rb][r] = fmaf(-2.0f * kSt, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(uT[rb][r] * k_inv1) + 1.0f), kSt);   // 2^13 t
+          for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(e[r]);
+          e = e + 1.0f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_rcpf(e[r]);
+          uT[rb] = e * (-2.0f * kSt) + kSt;   // 2^13 t
+#endif
+        }
+#ifndef OIVAE_ABL_NOPUB
         lds_wait_ge(f_con, pub, a.err);
         tr_write(uT[0], 0);
         tr_write(uT[1], 1);
         lds_post(f_pub, ++pub);
+#endif
         // ---- mu = W2 t + b2; gmu = (mu - x) inv / sigma^2; afterwards uT holds inv3 sd (1 - t^2) ----
         Frag2 tf[4];
         f32x16 gT[2];
         init_t(gT[0], sb2, 0);
         init_t(gT[1], sb2, 1);
         auto gmu_quarter = [&](int rb, int qq) {
-          const f32x4 c3 = *reinterpret_cast<const f32x4*>(sC3 + 32 * rb + 8 * qq + 4 * hh);
+          f32x4 c3n = *reinterpret_cast<const f32x4*>(sC3 + 32 * rb + 8 * qq + 4 * hh);   // - c3 in scaled units
+          if (partial) {   // rows past the end of the batch contribute nothing (a real, uniform branch: last tile only)
+            asm volatile("");
+            c3n *= liveT;
+          }
           const f32x4 x4 = xq[rb][qq];
-          xm = fmaxf(xm, fmaxf(fmaxf(fabsf(x4[0]), fabsf(x4[1])), fmaxf(fabsf(x4[2]), fabsf(x4[3]))));
+          asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(xm) : "v"(x4[0]), "v"(x4[1]));
+          asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(xm) : "v"(x4[2]), "v"(x4[3]));
+          if (rb == 0) {   // inside the product: scalar instructions (see below)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) gT[rb][4 * qq + i] = fmaf(gT[rb][4 * qq + i], k_inv2, -x4[i]) * (c3[i] * liveT);
+            for (int i = 0; i < 4; ++i) gT[rb][4 * qq + i] = fmaf(gT[rb][4 * qq + i], k_ninv2, x4[i]) * c3n[i];
+            return;
+          }
+          f32x4 gq4 = {gT[rb][4 * qq], gT[rb][4 * qq + 1], gT[rb][4 * qq + 2], gT[rb][4 * qq + 3]};
+          gq4 = (gq4 * k_ninv2 + x4) * c3n;   // (mu - x) c3 = (x - mu) (- c3)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) gT[rb][4 * qq + i] = gq4[i];
         };
         chain_mm(gT, [&](int rb, int ks) { return wfrag(imgl, 1, rb, ks); }, tf,
                  [&](int ks) {
                    const Frag2 f = afrag2n(uT[ks >> 1], ks & 1);
-                   if (ks & 1) {
+                   if (ks & 1) {   // (scalar on purpose: packed fp32 instructions between the matrix instructions of a product cost time)
 #pragma unroll
-                     for (int r = 0; r < 16; ++r) uT[ks >> 1][r] = fmaf(-(k_omtC / (kSt * kSt)) * uT[ks >> 1][r], uT[ks >> 1][r], k_omtC);
+                     for (int r = 0; r < 16; ++r) uT[ks >> 1][r] = fmaf(k_nomt2 * uT[ks >> 1][r], uT[ks >> 1][r], k_omtC);
                    }
                    return f;
                  },
                  [&](int u) { if (u >= 4) gmu_quarter(0, u - 4); });
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) gmu_quarter(1, qq);
+#ifndef OIVAE_ABL_NOPUB
         lds_wait_ge(f_con, pub, a.err);
         tr_write(gT[0], 0);
         tr_write(gT[1], 1);
         lds_post(f_pub, ++pub);
+#endif
         // ---- dt = W2^T gmu; da1 = dt (1 - t^2) ----
         Frag2 gf[4];
         f32x16 dT[2];
@@ -1989,12 +2078,13 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
                      for (int r = 4 * (u - 4); r < 4 * (u - 4) + 4; ++r) dT[0][r] *= uT[0][r];
                    }
                  });
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dT[1][r] *= uT[1][r];
+        dT[1] *= uT[1];
+#ifndef OIVAE_ABL_NOPUB
         lds_wait_ge(f_con, pub, a.err);
         tr_write(dT[0], 0);
         tr_write(dT[1], 1);
         lds_post(f_pub, ++pub);
+#endif
         {   // the next first product's operand, one product ahead: the same row tile's for the pair's second group
           const int tz = (h + 1 < ngrp) ? tile : tnext;
 #pragma unroll
@@ -2003,8 +2093,8 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
         // ---- dz^T[k][n] += sum_m A[m][k] da1[n][m], on top of the pair's first group (brought to this group's units) ----
         if (h == 1) {
           const float ratio = (q ? inv4[0] : inv4[1]) / (q ? inv4[1] : inv4[0]);   // powers of two: exact
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { dz[0][r] *= ratio; dz[1][r] *= ratio; }
+          dz[0] *= ratio;
+          dz[1] *= ratio;
         }
         Frag2 df[4];
         const bool last = h + 1 == ngrp;
@@ -2023,8 +2113,9 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
                    }
                  });
         if (last && liveRow) {
+          const f32x16 o16 = dz[1] * k_inv4;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) OIVAE_DZ_ADD(dz_row(32 + 8 * (r >> 2) + (r & 3)), dz[1][r] * k_inv4);
+          for (int r = 0; r < 16; ++r) OIVAE_DZ_ADD(dz_row(32 + 8 * (r >> 2) + (r & 3)), o16[r]);
         }
       }
     }
@@ -2052,18 +2143,38 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
         seen[j] += npub;
         f32x16 rd[2];
         Frag2 tNf[2][2];
+#ifdef OIVAE_ABL_NOWSPLIT   // timing only: the weight-gradient wave's splits replaced by one bit operation per pair
+        auto afrag2n = [&](const f32x16& v, int q) {
+          Frag2 f;
+          for (int e = 0; e < 4; ++e) { f.p[0][e] = __float_as_uint(v[8 * q + e]) & 0x3bff3bffu; f.p[1][e] = __float_as_uint(v[8 * q + 4 + e]) & 0x3bff3bffu; }
+          return f;
+        };
+#endif
+#ifdef OIVAE_ABL_NOWMFMA   // timing only: the weight-gradient wave without its matrix instructions
+        auto h2mm = [&](f32x16& acc, const Frag2& A, const Frag2& B) {
+          acc[0] += __uint_as_float((A.p[0][0] ^ B.p[1][0] ^ A.p[1][3] ^ B.p[0][3] ^ A.p[0][1] ^ A.p[0][2] ^ A.p[1][1] ^ A.p[1][2] ^ B.p[0][1] ^ B.p[0][2] ^ B.p[1][1] ^ B.p[1][2]) & 0x3fffffffu);
+        };
+#endif
         // ---- t ----
+#ifndef OIVAE_ABL_NOPUB
         lds_wait_ge(f_pub, n + 1, a.err);
+#endif
         rd[0] = tr_read(0);
         rd[1] = tr_read(1);
+#ifndef OIVAE_ABL_NOPUB
         lds_post(f_con, ++n);
+#endif
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) { tNf[mb][0] = afrag2n(rd[mb], 0); tNf[mb][1] = afrag2n(rd[mb], 1); }
         // ---- gmu: column sums, dW2[d][m] += sum_n gmu[n][d] t[n][m] ----
+#ifndef OIVAE_ABL_NOPUB
         lds_wait_ge(f_pub, n + 1, a.err);
+#endif
         rd[0] = tr_read(0);
         rd[1] = tr_read(1);
+#ifndef OIVAE_ABL_NOPUB
         lds_post(f_con, ++n);
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           float c1 = 0.f, c2 = 0.f;
@@ -2082,10 +2193,14 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
         Frag2 zn[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) zn[f] = zfrag2_of(tile, 4 + f);
+#ifndef OIVAE_ABL_NOPUB
         lds_wait_ge(f_pub, n + 1, a.err);
+#endif
         rd[0] = tr_read(0);
         rd[1] = tr_read(1);
+#ifndef OIVAE_ABL_NOPUB
         lds_post(f_con, ++n);
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           float csum = 0.f;
@@ -2113,7 +2228,9 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
     }
   }
   // ---- end of the kernel ----
+  OIVAE_PROBE(4);
   __syncthreads();
+  OIVAE_PROBE(5);
   // max|x| of the rows and columns this workgroup read: one atomic per workgroup
   if (chainw) {
 #pragma unroll
@@ -2228,6 +2345,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
       a.ll_part[(int64_t)chunk * a.G + gq] = tot;
     }
   }
+  OIVAE_PROBE(6);
 }
 
 // After a kernel that built its fp16 scales from rng[0] (the max|X| an earlier pass recorded) and recorded the
@@ -2392,3 +2510,9 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
 }
 
 }  // namespace oivae
+
+#ifdef OIVAE_ABL_TIMES
+extern "C" int oivae_probe_read(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(oivae::g_probe), sizeof(unsigned long long) * (size_t)n);
+}
+#endif

@@ -76,6 +76,20 @@ __device__ __forceinline__ Split2 split2_pair(float a, float b) {   // a, b alre
   r.l = __builtin_bit_cast(uint32_t, l);
   return r;
 }
+// The same split in four instructions per pair instead of six, for callers whose a, b are not themselves the result of
+// a multiplication the compiler can fuse: a - float(h) is written as a * one - float(h) with a 1.0 the compiler cannot
+// see through, which is one v_fma_mix_f32 (fp16 operand converted on the fly) instead of a conversion and a
+// subtraction, and as exact.  (The decoder's chain wave is bound by its vector instructions: -1 ms per launch.)
+__device__ __forceinline__ Split2 split2_pair_mix(float a, float b) {
+  Split2 r;
+  const x3_h16x2 h = __builtin_convertvector(x3_f32x2{a, b}, x3_h16x2);
+  float one = 1.0f;
+  asm("" : "+s"(one));
+  const x3_h16x2 l = __builtin_convertvector(x3_f32x2{__builtin_fmaf(a, one, -(float)h[0]), __builtin_fmaf(b, one, -(float)h[1])}, x3_h16x2);
+  r.h = __builtin_bit_cast(uint32_t, h);
+  r.l = __builtin_bit_cast(uint32_t, l);
+  return r;
+}
 __device__ __forceinline__ x3_f32x16 mfma_f16(x3_u32x4 a, x3_u32x4 b, x3_f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x3_h16x8, a), __builtin_bit_cast(x3_h16x8, b), c, 0, 0, 0);
 }
@@ -91,7 +105,7 @@ __device__ __forceinline__ void h2_scale_of(uint32_t absmax_bits, float* scale, 
 // one MFMA operand in its two fp16 terms (inputs already scaled)
 struct Frag2 { x3_u32x4 p[2]; };
 __device__ __forceinline__ Frag2 split8_h2(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
-  const Split2 a = split2_pair(v0, v1), b = split2_pair(v2, v3), c = split2_pair(v4, v5), d = split2_pair(v6, v7);
+  const Split2 a = split2_pair_mix(v0, v1), b = split2_pair_mix(v2, v3), c = split2_pair_mix(v4, v5), d = split2_pair_mix(v6, v7);
   Frag2 f;
   f.p[0] = x3_u32x4{a.h, b.h, c.h, d.h};
   f.p[1] = x3_u32x4{a.l, b.l, c.l, d.l};
