@@ -162,11 +162,18 @@ int oivae_decoder_fwd_bwd_f32(const oivae_shape_t* shape, const oivae_tensors_t*
 /* Layout of the dz buffer that oivae_decoder_fwd_bwd_f32 writes and oivae_encoder_bwd_f32 reads, for these
  * shapes and N = S*B rows: 0 = [N, K] row-major (sample-major rows), 1 = TRANSPOSED [K, N] (the matrix-core
  * decoders of the all-32 / all-64 generator shapes), negative = error.  Both entry points derive it the same way
- * from (shape, B, S) and the OIVAE_FORCE_GENERIC test switch; a host that reads dz, or feeds its own, asks here.
+ * from (shape, B, S) and the library's test hooks (below); a host that reads dz, or feeds its own, asks here.
  * dz is summed over the groups with float atomics by every decoder kernel except the flat (many-small-groups)
  * path, so it -- and the encoder gradients computed from it -- can differ in the last bits from run to run
  * (within 1e-5 of the tensor's scale: tests/test_gpu_dp.py); all other gradients are bit-reproducible. */
 int oivae_dz_layout(const oivae_shape_t* shape, int64_t B, int32_t S);
+
+/* Test hooks.  Three environment variables select other kernel families for cross-checks (no counterpart in the
+ * reference): OIVAE_FORCE_GENERIC (shape-generic kernels), OIVAE_ENC = bf16 | fp32, OIVAE_DEC = v1 | v4 | x3 | p | g.
+ * They are read when the library is first used, when oivae_init initialises a device, and when this function is
+ * called -- not on every call of an entry point, so the kernel choice (and dz's layout with it) cannot change
+ * between the calls of one step unless the host asks for it here. */
+void oivae_reload_test_hooks(void);
 
 /* ---- encoder backward -----------------------------------------------------
  * Replaces the encoder half of loss.backward() (lib/oivae.py:75):

@@ -21,7 +21,7 @@ SYMBOLS = [
   "oivae_init", "oivae_last_error", "oivae_version", "oivae_workspace_bytes",
   "oivae_prox_f32", "oivae_sgd_prox_f32", "oivae_prox_cols_f32", "oivae_encoder_fwd_f32",
   "oivae_decoder_fwd_bwd_f32", "oivae_encoder_bwd_f32", "oivae_finalize_f32",
-  "oivae_adam_f32", "oivae_encoder_bwd_noalloc_f32", "oivae_dz_layout",
+  "oivae_adam_f32", "oivae_encoder_bwd_noalloc_f32", "oivae_dz_layout", "oivae_reload_test_hooks",
 ]
 
 
@@ -80,10 +80,25 @@ def bind(path):
                                               c_vp, c_vp, c_vp, c_vp, c_vp]
   L.oivae_finalize_f32.argtypes = [PS, PT, PT, c_i64, c_i32, c_f, c_f, c_vp, c_vp, c_i64, c_vp]
   L.oivae_adam_f32.argtypes = [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_i32, c_f, c_vp]
+  L.oivae_reload_test_hooks.argtypes = []
+  L.oivae_reload_test_hooks.restype = None
   for name in ("oivae_prox_f32", "oivae_sgd_prox_f32", "oivae_prox_cols_f32", "oivae_encoder_fwd_f32", "oivae_decoder_fwd_bwd_f32",
                "oivae_encoder_bwd_f32", "oivae_finalize_f32", "oivae_adam_f32", "oivae_encoder_bwd_noalloc_f32"):
     getattr(L, name).restype = ctypes.c_int
   return L
+
+
+def set_test_hooks(**env):
+  """Set (value) or clear (None) the library's test-hook environment variables -- OIVAE_FORCE_GENERIC, OIVAE_ENC,
+  OIVAE_DEC -- and make the loaded library read them again (it does not look at the environment per call)."""
+  for k, v in env.items():
+    if k not in ("OIVAE_FORCE_GENERIC", "OIVAE_ENC", "OIVAE_DEC"):
+      raise KeyError(k)
+    if v is None:
+      os.environ.pop(k, None)
+    else:
+      os.environ[k] = str(v)
+  load().oivae_reload_test_hooks()
 
 
 def check(rc, what):

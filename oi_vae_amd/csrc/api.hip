@@ -262,6 +262,28 @@ using namespace oivae;
 extern "C" const char* oivae_last_error(void) { return g_err; }
 extern "C" const char* oivae_version(void) { return "oivae_hip 0.1 (gfx950)"; }
 
+// ---- test hooks: read from the environment at first use, at each device's oivae_init and on request ----
+namespace oivae {
+static TestHooks read_test_hooks() {
+  TestHooks h{};
+  h.force_generic = getenv("OIVAE_FORCE_GENERIC") != nullptr;
+  const char* e = getenv("OIVAE_ENC");
+  h.enc = (e && (e[0] == 'b' || e[0] == 'f')) ? e[0] : 0;
+  const char* d = getenv("OIVAE_DEC");
+  h.dec[0] = d ? d[0] : 0;
+  h.dec[1] = (d && d[0]) ? d[1] : 0;
+  return h;
+}
+static TestHooks& hooks_storage() {
+  static TestHooks h = read_test_hooks();
+  return h;
+}
+const TestHooks& test_hooks() { return hooks_storage(); }
+void reload_test_hooks() { hooks_storage() = read_test_hooks(); }
+}  // namespace oivae
+
+extern "C" void oivae_reload_test_hooks(void) { reload_test_hooks(); }
+
 extern "C" int oivae_init(int device) {
   if (device < 0 || device >= kMaxDevices) return fail(OIVAE_E_ARG, "oivae_init: bad device %d", device);
   std::lock_guard<std::mutex> lk(g_init_mu);
@@ -286,7 +308,7 @@ extern "C" int oivae_init(int device) {
     if (e != hipSuccess) rc = fail(OIVAE_E_HIP, "oivae_init: error word: %s", hipGetErrorString(e));
     else { g_err_host[device] = static_cast<uint32_t*>(h); g_err_dev[device] = static_cast<uint32_t*>(dp); }
   }
-  if (rc == OIVAE_OK) g_tab[device] = d;
+  if (rc == OIVAE_OK) { g_tab[device] = d; reload_test_hooks(); }
   else if (d) (void)hipFree(d);
   (void)hipSetDevice(prev);   // also on the error paths
   return rc;

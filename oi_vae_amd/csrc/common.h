@@ -113,6 +113,16 @@ inline int64_t enc_bwd_part_bytes(const oivae_shape_t& s, int64_t B, bool x3_bwd
   return sp > 1 ? (int64_t)sizeof(float) * sp * 2 * s.K * s.D : 0;
 }
 // x3_encoder.hip: fp32 GEMMs as six bf16 matrix products
+// Test hooks (kernel-family switches for cross-checks): OIVAE_FORCE_GENERIC, OIVAE_ENC, OIVAE_DEC are read from the
+// environment by oivae_init and by oivae_reload_test_hooks, never per call: the kernel choice -- and with it dz's
+// layout -- cannot change between the decoder call and the encoder backward call of a step behind the host's back.
+struct TestHooks {
+  bool force_generic;   // OIVAE_FORCE_GENERIC set: shape-generic kernels everywhere
+  char enc;             // OIVAE_ENC: 0 default (fp16 terms), 'b' bf16 terms, 'f' fp32 matrix instructions
+  char dec[2];          // OIVAE_DEC: first two characters (v1, v4, x3, p, g), 0 when unset
+};
+const TestHooks& test_hooks();
+void reload_test_hooks();
 bool x3_encoder_applies(const oivae_shape_t& s);
 int64_t x3_encoder_ws_bytes(const oivae_shape_t& s, int64_t B);
 int64_t x3_encoder_bwd_img_bytes(const oivae_shape_t& s, int64_t B);  // image of dpre^T alone (0 when the x3 backward kernels do not apply)

@@ -25,7 +25,7 @@ constexpr int kFlatGB = 16;  // groups per block of the group kernel
 constexpr int kFlatRL = 16;  // row lanes per block
 
 bool flat_decoder_applies(const oivae_shape_t& s, int64_t N) {
-  if (getenv("OIVAE_FORCE_GENERIC")) return false;  // test hook
+  if (test_hooks().force_generic) return false;  // test hook
   if (s.gen_type == OIVAE_GEN_MLP) return false;
   const int dg = s.uniform_group_dim;
   if (!((dg == 4 || dg == 8) && (s.H == 4 || s.H == 8))) return false;

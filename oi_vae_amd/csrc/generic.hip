@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void dec_single(DecArgs a) {
 }
 
 bool single_decoder_applies(const oivae_shape_t& s) {
-  if (getenv("OIVAE_FORCE_GENERIC")) return false;
+  if (test_hooks().force_generic) return false;
   if (s.gen_type == OIVAE_GEN_MLP) return false;
   if (!(s.H == 1 || s.H == 2 || s.H == 4 || s.H == 8) || s.K > 128) return false;
   return single_decoder_lds_bytes(s) <= 120 * 1024;

@@ -2372,7 +2372,7 @@ __global__ __launch_bounds__(256) void gated_zero_f32(float* __restrict__ p, int
 }
 
 bool mfma_decoder_applies(const oivae_shape_t& s) {
-  if (getenv("OIVAE_FORCE_GENERIC")) return false;  // test hook: cross-check the two kernel families
+  if (test_hooks().force_generic) return false;  // test hook: cross-check the two kernel families
   if (s.gen_type != OIVAE_GEN_MLP) return false;
   const int dg = s.uniform_group_dim;
   const bool all64 = (s.K == 64 && s.H == 64 && s.M == 64 && dg == 64);
@@ -2433,7 +2433,7 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   a.zimg = nullptr;
   a.rng = nullptr;
   int rc;
-  const char* dec_env = getenv("OIVAE_DEC");
+  const char* dec_env = test_hooks().dec[0] ? test_hooks().dec : nullptr;
   // test hooks: OIVAE_DEC=v1 the layer-by-layer fp32 template kernel (which also serves launches whose dz image
   // exceeds the 32-bit byte offsets of dec_mfma64_v4's atomics, N*K*4 >= 2^32), OIVAE_DEC=v4 the fp32
   // composed-first-layer kernel, OIVAE_DEC=x3 the single-wave-per-SIMD split-bf16 kernel, OIVAE_DEC=p the all-bf16

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void enc_bwd_gemm(const flo
 }
 
 bool mfma_encoder_applies(const oivae_shape_t& s) {
-  if (getenv("OIVAE_FORCE_GENERIC")) return false;  // test hook
+  if (test_hooks().force_generic) return false;  // test hook
   // 16-byte alignment of the rows of X ([B, D]) and of dpre ([B, 2K]); partial tiles are masked
   return (s.D % 4 == 0) && s.D >= 32 && (s.K % 2 == 0);
 }

@@ -726,8 +726,7 @@ bool mfma_encoder_applies(const oivae_shape_t& s);  // mfma_encoder.hip
 
 bool x3_encoder_applies(const oivae_shape_t& s) {
   if (!mfma_encoder_applies(s)) return false;
-  const char* e = getenv("OIVAE_ENC");  // test hook: OIVAE_ENC=fp32 keeps the fp32 matrix instructions
-  if (e && e[0] == 'f') return false;
+  if (test_hooks().enc == 'f') return false;  // test hook: OIVAE_ENC=fp32 keeps the fp32 matrix instructions
   return (2 * s.K) % 128 == 0 && s.D % 32 == 0;
 }
 
@@ -765,7 +764,7 @@ int x3_encoder_fwd_splits(const oivae_shape_t& s, int64_t B) {
 // of two and a gated second launch repeats the kernel when they differ.  No host-side memory of earlier calls: every
 // entry point is a function of its arguments and computes with the scale of its own X's maximum.
 // test hook: OIVAE_ENC=bf16 keeps the three-term bf16 kernels
-static inline bool h2_enabled() { const char* e = getenv("OIVAE_ENC"); return !(e && e[0] == 'b'); }
+static inline bool h2_enabled() { return test_hooks().enc != 'b'; }
 void launch_range_guard(uint32_t* rng, int seen, int flag, hipStream_t st);  // mfma_decoder.hip
 
 int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params, const float* X, int64_t B,

@@ -13,6 +13,8 @@ import numpy as np
 import pytest
 import torch
 
+from oi_vae_amd import _lib
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -262,17 +264,14 @@ def test_full_wide_prox_shape_whole_step():
   eps = torch.randn(1, B, K, generator=g, device="cuda")
   res = {}
   try:
-    for mode in ("generic", "flat"):              # the library reads the switch on every call
-      if mode == "generic":
-        os.environ["OIVAE_FORCE_GENERIC"] = "1"
-      else:
-        os.environ.pop("OIVAE_FORCE_GENERIC", None)
+    for mode in ("generic", "flat"):
+      _lib.set_test_hooks(OIVAE_FORCE_GENERIC="1" if mode == "generic" else None)
       eng._ws_key = None
       out = eng.forward_backward(X, eps, 1.0)
       torch.cuda.synchronize()
       res[mode] = (eng.flat_grads.double().cpu().clone(), out["scalars"].double().cpu().clone())
   finally:
-    os.environ.pop("OIVAE_FORCE_GENERIC", None)
+    _lib.set_test_hooks(OIVAE_FORCE_GENERIC=None)
   a, b = res["flat"], res["generic"]
   assert torch.isfinite(a[0]).all()
   assert float(((a[1][:6] - b[1][:6]).abs() / b[1][:6].abs().clamp(min=1.0)).max()) < 1e-5
@@ -320,16 +319,13 @@ def test_single_layer_decoder_agrees_with_generic(typ, H, K):
   res = {}
   try:
     for mode in ("generic", "single", "single_again"):
-      if mode == "generic":
-        os.environ["OIVAE_FORCE_GENERIC"] = "1"
-      else:
-        os.environ.pop("OIVAE_FORCE_GENERIC", None)
+      _lib.set_test_hooks(OIVAE_FORCE_GENERIC="1" if mode == "generic" else None)
       eng._ws_key = None
       out = eng.forward_backward(X, eps, 0.8)
       torch.cuda.synchronize()
       res[mode] = (eng.flat_grads.double().cpu().clone(), out["scalars"].double().cpu().clone())
   finally:
-    os.environ.pop("OIVAE_FORCE_GENERIC", None)
+    _lib.set_test_hooks(OIVAE_FORCE_GENERIC=None)
   a, b = res["single"], res["generic"]
   assert torch.isfinite(a[0]).all()
   assert float(((a[1][:6] - b[1][:6]).abs() / b[1][:6].abs().clamp(min=1.0)).max()) < 1e-5

@@ -2,7 +2,7 @@
 default, two scaled fp16 terms and three fp16 matrix products per fp32 product ("x3" below, the library's default
 mode), and three bf16 terms with six products (OIVAE_ENC=bf16).  The claim under test: the result is fp32-grade --
 against a float64 product of the same fp32 inputs its error is no larger than that of the fp32 matrix
-instructions (OIVAE_ENC=fp32 selects those; the library reads the variable on every call).
+instructions (OIVAE_ENC=fp32 selects those; `_lib.set_test_hooks` makes the library read the variable again).
 Tolerances: 5e-6 of the result's largest magnitude absolute, and at most 2x the fp32 path's own error + 1e-6."""
 import ctypes
 import os
@@ -14,17 +14,19 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _hooks(**env):
+  from oi_vae_amd import _lib
+  _lib.set_test_hooks(**env)
+
+
 def _mode(name):
-  if name in ("fp32", "bf16"):
-    os.environ["OIVAE_ENC"] = name
-  else:
-    os.environ.pop("OIVAE_ENC", None)
+  _hooks(OIVAE_ENC=name if name in ("fp32", "bf16") else None)
 
 
 @pytest.fixture(autouse=True)
 def _restore_env():
   yield
-  os.environ.pop("OIVAE_ENC", None)
+  _hooks(OIVAE_ENC=None, OIVAE_DEC=None)
 
 
 def _engine(D, K, seed):
@@ -168,8 +170,7 @@ def test_decoder_gradients_are_fp32_grade():
 
   err = {}
   for mode in ("v4", "x3", "default"):
-    os.environ["OIVAE_DEC"] = mode
-    if mode == "default": os.environ.pop("OIVAE_DEC")
+    _hooks(OIVAE_DEC=None if mode == "default" else mode)
     eng._ws_key = None
     ws = eng._workspace(B, S)
     eng.flat_grads.fill_(float("nan"))
@@ -182,7 +183,7 @@ def test_decoder_gradients_are_fp32_grade():
       got = eng.g[n].double().cpu().view_as(want[n])
       e[n] = float((got - want[n]).abs().max() / want[n].abs().max())
     err[mode] = e
-  os.environ.pop("OIVAE_DEC", None)
+  _hooks(OIVAE_DEC=None)
   for mode in ("x3", "default"):
     for n in err[mode]:
       assert err[mode][n] <= 5e-6, (mode, n, err)
@@ -201,15 +202,12 @@ def test_paired_decoder_tiny_batches(B, S):
   eps = torch.randn(S, B, 64, generator=g, device="cuda")
   res = {}
   for mode in ("v4", None):
-    if mode is None:
-      os.environ.pop("OIVAE_DEC", None)
-    else:
-      os.environ["OIVAE_DEC"] = mode
+    _hooks(OIVAE_DEC=mode)
     eng._ws_key = None
     out = eng.forward_backward(X, eps, 0.9)
     torch.cuda.synchronize()
     res[mode] = (eng.flat_grads.double().cpu().clone(), out["scalars"].double().cpu().clone())
-  os.environ.pop("OIVAE_DEC", None)
+  _hooks(OIVAE_DEC=None)
   a, b = res[None], res["v4"]
   assert torch.isfinite(a[0]).all()
   assert float(((a[1][:6] - b[1][:6]).abs() / b[1][:6].abs().clamp(min=1.0)).max()) < 1e-5
@@ -345,10 +343,9 @@ def test_fp16_chain_decoder_step_against_float64(case):
   err = {}
   for mode in ("fp32", "default"):
     if mode == "fp32":
-      os.environ["OIVAE_ENC"], os.environ["OIVAE_DEC"] = "fp32", "v4"
+      _hooks(OIVAE_ENC="fp32", OIVAE_DEC="v4")
     else:
-      os.environ.pop("OIVAE_ENC", None)
-      os.environ.pop("OIVAE_DEC", None)
+      _hooks(OIVAE_ENC=None, OIVAE_DEC=None)
     eng._ws_key = None
     eng.forward_backward(X, eps, 0.7)
     torch.cuda.synchronize()
@@ -359,8 +356,7 @@ def test_fp16_chain_decoder_step_against_float64(case):
       assert torch.isfinite(got).all(), (mode, n)
       e[n] = float((got - want).abs().max() / want.abs().max().clamp(min=1e-30))   # x_zero: exact zeros expected
     err[mode] = e
-  os.environ.pop("OIVAE_ENC", None)
-  os.environ.pop("OIVAE_DEC", None)
+  _hooks(OIVAE_ENC=None, OIVAE_DEC=None)
   # saturated_tanh: 1 - t^2 cancels in fp32 whoever computes it (the reference's tanh backward too); there the
   # fp32-instruction kernels' own error against float64 (3e-5) is the bar
   bar = 2e-5 if case != "saturated_tanh" else 5e-5

@@ -8,11 +8,12 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.test_gpu_scale import _engine  # noqa: E402
+from tests.test_gpu_scale import _engine
+from oi_vae_amd import _lib  # noqa: E402
 
 
 def setmode(m):
-  os.environ["OIVAE_DEC"] = m
+  _lib.set_test_hooks(OIVAE_DEC=m)
 
 
 def agree():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Accuracy (against float64) and time of the bf16x3-split encoder GEMMs beside the fp32-MFMA ones.
-OIVAE_ENC=fp32 is read by the library on every call, so both run in one process on the same inputs."""
+OIVAE_ENC=fp32 selects the latter (`_lib.set_test_hooks`), so both run in one process on the same inputs."""
 import os
 import sys
 
@@ -12,10 +12,7 @@ from tests.test_gpu_scale import _engine  # noqa: E402
 
 
 def run(eng, X, eps, mode):
-  if mode == "fp32":
-    os.environ["OIVAE_ENC"] = "fp32"
-  else:
-    os.environ.pop("OIVAE_ENC", None)
+  _lib.set_test_hooks(OIVAE_ENC="fp32" if mode == "fp32" else None)
   eng._ws_key = None
   out = eng.forward_backward(X, eps, 1.0)
   torch.cuda.synchronize()
@@ -57,10 +54,7 @@ def backward_accuracy():
   pm, ps = torch.zeros(1, K, device="cuda"), torch.ones(1, K, device="cuda")
   want = (dzT.double() @ X.double()).cpu()
   for mode in ("fp32", "x3"):
-    if mode == "fp32":
-      os.environ["OIVAE_ENC"] = "fp32"
-    else:
-      os.environ.pop("OIVAE_ENC", None)
+    _lib.set_test_hooks(OIVAE_ENC="fp32" if mode == "fp32" else None)
     eng._ws_key = None
     ws = eng._workspace(B, 1)
     eng.flat_grads.zero_()
@@ -81,10 +75,7 @@ def timing():
   X = torch.rand(B, G * dg, generator=g, device="cuda")
   eps = torch.randn(1, B, K, generator=g, device="cuda")
   for mode in ("fp32", "x3", "fp32", "x3"):
-    if mode == "fp32":
-      os.environ["OIVAE_ENC"] = "fp32"
-    else:
-      os.environ.pop("OIVAE_ENC", None)
+    _lib.set_test_hooks(OIVAE_ENC="fp32" if mode == "fp32" else None)
     eng._ws_key = None
     eng.forward_backward(X, eps, 1.0)
     eng.trace = []
