@@ -1959,6 +1959,22 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
     volatile uint32_t* f_pub = flags + 2 * sw;
     volatile uint32_t* f_con = flags + 2 * sw + 1;
     uint32_t pub = 0;
+    // Hand-over of a tile, chain side.  The "consumed" counter is requested BEFORE the elementwise work that produces
+    // the tile and looked at after it (its LDS latency is hidden; the polling loop only runs when the other wave is
+    // late), and the "published" counter is bumped right behind the tile's stores with no wait in between: a wave's
+    // LDS instructions are performed in order, so whoever sees the counter sees the tile.
+    typedef const volatile __attribute__((address_space(3))) uint32_t* lds_cu32;
+    typedef volatile __attribute__((address_space(3))) uint32_t* lds_u32;
+    auto con_peek = [&]() { return *(lds_cu32)f_con; };
+    auto publish = [&](const f32x16& v0, const f32x16& v1, uint32_t peeked) {
+      if ((uint32_t)__builtin_amdgcn_readfirstlane(peeked) < pub) lds_wait_ge(f_con, pub, a.err);
+      tr_write(v0, 0);
+      tr_write(v1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+      *(lds_u32)f_pub = ++pub;
+      __builtin_amdgcn_sched_barrier(0);   // or the scheduler sinks the store below the MFMAs that follow: the partner waits
+    };
     char* const dzb = reinterpret_cast<char*>(a.dzT);
     const int64_t rowbytes = a.N * 4;
     Frag2 zf[4];
@@ -2004,6 +2020,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
         chain_mm(uT, [&](int rb, int ks) { return wfrag(imgl, 0, rb, ks); }, zf, [&](int ks) { return zf[ks]; }, none);
         // ---- t = tanh: published first, split during the next product ----
         // (whole-vector expressions: the compiler turns them into packed fp32 instructions, two elements each)
+        uint32_t peek = con_peek();
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
 #ifdef OIVAE_ABL_NOTANH
@@ -2019,10 +2036,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
 #endif
         }
 #ifndef OIVAE_ABL_NOPUB
-        lds_wait_ge(f_con, pub, a.err);
-        tr_write(uT[0], 0);
-        tr_write(uT[1], 1);
-        lds_post(f_pub, ++pub);
+        publish(uT[0], uT[1], peek);
 #endif
         // ---- mu = W2 t + b2; gmu = (mu - x) inv / sigma^2; afterwards uT holds inv3 sd (1 - t^2) ----
         Frag2 tf[4];
@@ -2058,13 +2072,11 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
                    return f;
                  },
                  [&](int u) { if (u >= 4) gmu_quarter(0, u - 4); });
+        peek = con_peek();
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) gmu_quarter(1, qq);
 #ifndef OIVAE_ABL_NOPUB
-        lds_wait_ge(f_con, pub, a.err);
-        tr_write(gT[0], 0);
-        tr_write(gT[1], 1);
-        lds_post(f_pub, ++pub);
+        publish(gT[0], gT[1], peek);
 #endif
         // ---- dt = W2^T gmu; da1 = dt (1 - t^2) ----
         Frag2 gf[4];
@@ -2078,12 +2090,10 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
                      for (int r = 4 * (u - 4); r < 4 * (u - 4) + 4; ++r) dT[0][r] *= uT[0][r];
                    }
                  });
+        peek = con_peek();
         dT[1] *= uT[1];
 #ifndef OIVAE_ABL_NOPUB
-        lds_wait_ge(f_con, pub, a.err);
-        tr_write(dT[0], 0);
-        tr_write(dT[1], 1);
-        lds_post(f_pub, ++pub);
+        publish(dT[0], dT[1], peek);
 #endif
         {   // the next first product's operand, one product ahead: the same row tile's for the pair's second group
           const int tz = (h + 1 < ngrp) ? tile : tnext;

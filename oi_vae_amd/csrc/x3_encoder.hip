@@ -292,7 +292,7 @@ __global__ __launch_bounds__(768, 1) void enc_x3_gemm(const float* __restrict__ 
 // barrier schedule as enc_x3_gemm<true>; LDS rows are 20 dwords (2 pieces x 8 + 4 pad: conflict-free 16-byte reads).
 // ------------------------------------------------------------------------------
 constexpr int kH2Row = 20;
-constexpr int kH2Sub = 128 * kH2Row + 32;
+constexpr int kH2Sub = 128 * kH2Row + 16;   // sub-step images 16 banks apart (stores bank over 32 dwords): the producers' stores stay conflict-free
 constexpr int kH2Buf = 4 * kH2Sub;
 
 __global__ __launch_bounds__(256) void absmax_f32(const float* __restrict__ v, int64_t n, uint32_t* __restrict__ out) {
