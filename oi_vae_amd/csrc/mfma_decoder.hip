@@ -1673,7 +1673,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64p(MfmaDecArgs a) {
 constexpr int kPairImg = 2 * 3 * 4096;   // dwords: [group][A | W2 | W2^T][2 rb][4 ks][2 terms][64 lanes][4]
 constexpr int kPairVec = 2 * 192;        // floats: per group b1, b2, c3 in scaled units
 constexpr int kPairTile = 32 * 68;       // floats: one chain wave's published tile
-constexpr int kPairScr = 3 * 64 * 65 + 128;   // set-up staging 3 x [64][65]; row loop: four tiles
+constexpr int kPairScr = 3 * 64 * 65 + 64 + 512;   // set-up staging 3 x [64][65] + bounds + partials; row loop: four tiles
 constexpr int kPairLds = (kPairImg + kPairVec + kPairScr + 64) * 4;
 static_assert(kPairScr >= 4 * kPairTile, "tiles");
 static_assert(kPairImg >= 2 * 4096 + 3 * 64 * 65 + 2 * 192, "end-of-kernel staging");
@@ -1720,6 +1720,20 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
   float inv1[2] = {1.f, 1.f}, inv2[2] = {1.f, 1.f}, inv4[2] = {1.f, 1.f}, omtC[2] = {1.f, 1.f};
   float invW[2] = {1.f, 1.f}, invP[2] = {1.f, 1.f}, invG[2] = {1.f, 1.f}, invD[2] = {1.f, 1.f};
   if (tid < 64) flags[tid] = 0;
+  // the three weight matrices of both groups: requested up front, 16 bytes per lane (the latency of global memory is
+  // paid once per workgroup, not once per loop iteration and group)
+  f32x4 pre[2][3][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int gq = (2 * pairIdx + q < a.G) ? 2 * pairIdx + q : 2 * pairIdx;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = 4 * (tid + 512 * j);
+      pre[q][0][j] = *reinterpret_cast<const f32x4*>(a.W1 + (int64_t)gq * M * H + e);
+      pre[q][1][j] = *reinterpret_cast<const f32x4*>(a.Ws + (int64_t)gq * K * H + e);
+      pre[q][2][j] = *reinterpret_cast<const f32x4*>(a.W2 + (int64_t)gq * DG * M + e);
+    }
+  }
   for (int q = 0; q < 2; ++q) {   // set-up of the pair's groups, one after the other through the same staging
     const int gq = 2 * pairIdx + q;
     if (gq >= a.G) break;
@@ -1729,15 +1743,17 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
     float* tW1 = scr;
     float* tWs = scr + 64 * LW;
     float* tW2 = scr + 2 * 64 * LW;
-    const float* Wsg = a.Ws + (int64_t)gq * K * H;
-    const float* W1g = a.W1 + (int64_t)gq * M * H;
-    const float* W2g = a.W2 + (int64_t)gq * DG * M;
     __syncthreads();
-    for (int i = tid; i < 4096; i += 512) {
-      const int o = (i >> 6) * LW + (i & 63);
-      tW1[o] = W1g[i];
-      tWs[o] = Wsg[i];
-      tW2[o] = W2g[i];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = 4 * (tid + 512 * j);
+      const int o = (e >> 6) * LW + (e & 63);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        tW1[o + i] = q ? pre[1][0][j][i] : pre[0][0][j][i];
+        tWs[o + i] = q ? pre[1][1][j][i] : pre[0][1][j][i];
+        tW2[o + i] = q ? pre[1][2][j][i] : pre[0][2][j][i];
+      }
     }
     if (tid < 64) {
       const float sig = expf(a.ls[(int64_t)gq * DG + tid]) + a.sig_off;
@@ -1778,18 +1794,36 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
       }
       atomicMax(red + 0, __float_as_uint(mA));
       atomicMax(red + 1, __float_as_uint(mW));
-      if (tid < 64) {
-        float rs = fabsf(sb2[tid]) + __uint_as_float(a.rng[0]);
-        for (int m = 0; m < 64; ++m) rs += fabsf(tW2[tid * LW + m]);
-        const float gb = sC3[tid] * rs;
-        gbound[tid] = gb;
-        atomicMax(red + 2, __float_as_uint(gb));
+      {   // eight lanes per output dimension d: sum_m |W2[d][m]|
+        const int d = tid >> 3, part = tid & 7;
+        float rs = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) rs += fabsf(tW2[d * LW + 8 * m + part]);
+        rs += __shfl_xor(rs, 1);
+        rs += __shfl_xor(rs, 2);
+        rs += __shfl_xor(rs, 4);
+        if (part == 0) {
+          const float gb = sC3[d] * (rs + fabsf(sb2[d]) + __uint_as_float(a.rng[0]));
+          gbound[d] = gb;
+          atomicMax(red + 2, __float_as_uint(gb));
+        }
       }
     }
     __syncthreads();
-    if (tid < 64) {
+    {   // eight lanes per hidden unit m: sum_d |W2[d][m]| gbound[d]
+      const int m = tid & 63, part = tid >> 6;
       float cs = 0.f;
-      for (int d = 0; d < 64; ++d) cs += fabsf(tW2[d * LW + tid]) * gbound[d];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) cs += fabsf(tW2[(8 * part + d) * LW + m]) * gbound[8 * part + d];
+      float* csp = scr + 3 * 64 * LW + 64;   // [8][64] partials behind gbound
+      csp[part * 64 + m] = cs;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const float* csp = scr + 3 * 64 * LW + 64;
+      float cs = 0.f;
+#pragma unroll
+      for (int p8 = 0; p8 < 8; ++p8) cs += csp[p8 * 64 + tid];
       atomicMax(red + 3, __float_as_uint(cs));
     }
     __syncthreads();
@@ -2349,10 +2383,11 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
       sred[wtid] = nrows * (-0.5f * kLog2Pi - logf(sig)) - 0.5f * sumq2;
     }
     __syncthreads();
-    if (worker && wtid == 0) {
-      double tot = 0.0;
-      for (int i = 0; i < 64; ++i) tot += (double)sred[i];
-      a.ll_part[(int64_t)chunk * a.G + gq] = tot;
+    if (worker && wtid < 64) {   // one wave: 64 terms summed in double, in a fixed tree order
+      double tot = (double)sred[wtid];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+      if (wtid == 0) a.ll_part[(int64_t)chunk * a.G + gq] = tot;
     }
   }
   OIVAE_PROBE(6);
@@ -2458,7 +2493,10 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   // of earlier calls.
   // (its atomics address dz with 32-bit byte offsets: larger launches take the bf16 pair)
   const bool fits32 = N * (int64_t)s.K * 4 < ((int64_t)1 << 32);
-  const bool use_g = s.K == 64 && fits32 && (dec_env == nullptr || dec_env[0] == 'g');
+  // (it also fetches the generator matrices 16 bytes per lane: parameters that are not 16-byte aligned take the bf16 pair)
+  const bool aligned16 = ((reinterpret_cast<uintptr_t>(params->gen_W1) | reinterpret_cast<uintptr_t>(params->gen_W2) |
+                           reinterpret_cast<uintptr_t>(params->Ws)) & 15) == 0;
+  const bool use_g = s.K == 64 && fits32 && aligned16 && (dec_env == nullptr || dec_env[0] == 'g');
   uint32_t* rng = w.ranges;
   a.G = s.G;
   a.err = error_word_device();
