@@ -54,3 +54,81 @@ def test_bucketed_grad_sync_on_one_rank_rccl(tmp_path):
   env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
   r = subprocess.run([sys.executable, str(script), port], capture_output=True, text=True, timeout=110, env=env)
   assert r.returncode == 0, r.stdout + r.stderr
+
+
+_WORKER2 = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from oi_vae_amd import parallel
+from tests.test_gpu_scale import _engine
+rank, port = int(sys.argv[1]), sys.argv[2]
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=2)
+G, B, K, steps = 6, 512, 64, 3
+g = torch.Generator(device="cuda").manual_seed(21)
+Xs = [torch.rand(B, G * 64, generator=g, device="cuda") for _ in range(steps)]
+Es = [torch.randn(1, B, K, generator=g, device="cuda") for _ in range(steps)]
+lo, hi = parallel.shard_rows(B, rank, 2)
+t_prox = 7.5   # rows of Ws ~ N(0,1)^64 have norm ~8: a good third of them dies at the first step
+
+def run(eng, rows, sync_on):
+  scal = []
+  for X, eps in zip(Xs, Es):
+    sync = parallel.BucketedGradSync(eng) if sync_on else None
+    out = eng.forward_backward(X[rows].contiguous(), eps[:, rows].contiguous(), 1.0, lam=1.0, grad_sync=sync)
+    sc = out["scalars"].clone()
+    if sync_on:
+      sync.wait()
+      parallel.reduce_scalars_(sc)
+    eng.adam_step(1e-3)
+    eng.sgd_prox_step(1e-3, t_prox)
+    scal.append(sc[:6].double().cpu())
+  torch.cuda.synchronize()
+  return torch.stack(scal)
+
+eng = _engine(G, 64, K, 64, 64, seed=5)
+sc_dp = run(eng, slice(lo, hi), True)
+mine = eng.flat_params.clone()
+# both ranks must hold bit-identical parameters (and so the same zero set) after every step's all-reduce
+both = [torch.empty_like(mine), torch.empty_like(mine)]
+dist.all_gather(both, mine)
+assert torch.equal(both[0], both[1]), "ranks diverged"
+if rank == 0:
+  ref = _engine(G, 64, K, 64, 64, seed=5)
+  sc_1 = run(ref, slice(0, B), False)
+  assert float(((sc_dp - sc_1).abs() / sc_1.abs().clamp(min=1.0)).max()) < 1e-5, (sc_dp, sc_1)
+  for n in ref.seg_off:
+    o, m = ref.seg_off[n], ref.seg_numel[n]
+    if m:
+      a, b = mine[o:o + m], ref.flat_params[o:o + m]
+      assert float((a - b).abs().max() / b.abs().max().clamp(min=1e-30)) < 2e-5, n
+  wa, wb = eng.p["Ws"], ref.p["Ws"]
+  dead_a, dead_b = (wa == 0).all(-1), (wb == 0).all(-1)
+  assert int(dead_b.sum()) > 0, "the threshold should kill some rows"
+  assert int((dead_a != dead_b).sum()) <= 2     # a row within rounding of the threshold may fall either way
+dist.barrier()
+dist.destroy_process_group()
+print("ok")
+'''
+
+
+def test_two_ranks_on_one_gpu_match_the_single_rank_step(tmp_path):
+  """World size 2 over gloo with both ranks on cuda:0: each rank runs the real kernels on its half of the batch,
+  the two gradient buckets are averaged as in a multi-GPU run, optimizers and the proximal step follow.  Both ranks
+  must end with bit-identical parameters, and those must be the single-rank full-batch step's within rounding."""
+  script = tmp_path / "dp2.py"
+  script.write_text(_WORKER2 % {"root": ROOT})
+  port = str(31600 + (os.getpid() % 2000))
+  env = dict(os.environ)
+  procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                            text=True, env=env) for r in range(2)]
+  outs = []
+  for p in procs:
+    try:
+      o, _ = p.communicate(timeout=110)
+    except subprocess.TimeoutExpired:
+      p.kill()
+      o, _ = p.communicate()
+    outs.append(o)
+  assert all(p.returncode == 0 for p in procs), "\n".join(outs)
