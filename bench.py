@@ -165,12 +165,22 @@ def main():
   if world != args.gpus:
     if world == 1 and args.gpus > 1:
       raise SystemExit("launch with torchrun --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-  torch.cuda.set_device(local_rank)
-  device = torch.device("cuda", local_rank)
+  # OIVAE_BENCH_REHEARSE=1: all ranks on cuda:0 over gloo -- walks the N > 1 code path (sharding, the two gradient
+  # buckets, barriers, max over ranks, rank 0's line) on a one-GPU box; its numbers mean nothing and the line says so
+  rehearse = os.environ.get("OIVAE_BENCH_REHEARSE") == "1"
+  if rehearse:
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=False, file=sys.stderr)   # a hang names its line
+  dev_index = 0 if rehearse else local_rank
+  torch.cuda.set_device(dev_index)
+  device = torch.device("cuda", dev_index)
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=device)
+    if rehearse:
+      dist.init_process_group("gloo")
+    else:
+      dist.init_process_group("nccl", device_id=device)
   from oi_vae_amd import parallel
 
   rows = GLOBAL_BATCH // world
@@ -308,6 +318,8 @@ def main():
                     "three bf16 terms, six products); extra.ms_per_step_fp32_matrix_instructions: OIVAE_ENC=fp32 "
                     "OIVAE_DEC=v4",
     }
+    if rehearse:
+      out["rehearsal"] = "all %d ranks on one GPU over gloo: code-path check only, the numbers are meaningless" % world
     if world == 1:
       out["prox_roofline"] = prox_roofline(device)
     if world == 1 and not args.no_cpu_baseline:

@@ -74,6 +74,15 @@ class BucketedGradSync:
     if not self.active or t.numel() == 0:
       return
     op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+    if not self._avg and t.is_cuda:
+      # gloo with device tensors (two ranks sharing a GPU in tests and rehearsals; never the production backend):
+      # on this ROCm stack a gloo collective issued while kernels are still in flight can hang in its own stream
+      # synchronisation (seen at the 8192-row shard size; the kernels themselves had finished), so drain first
+      # and run the collective to its end before the next kernel is launched
+      torch.cuda.synchronize(t.device)
+      dist.all_reduce(t, op=op, group=self.group)
+      self._scale_pending = True
+      return
     self._pending.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
 
   def decoder_grads_ready(self):
@@ -85,7 +94,8 @@ class BucketedGradSync:
   def wait(self):
     for w in self._pending:
       w.wait()
-    had = bool(self._pending)
+    had = bool(self._pending) or getattr(self, "_scale_pending", False)
     self._pending = []
+    self._scale_pending = False
     if had and not self._avg:
       self.flat.mul_(1.0 / self.world)

@@ -65,7 +65,7 @@ from tests.test_gpu_scale import _engine
 rank, port = int(sys.argv[1]), sys.argv[2]
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=2)
-G, B, K, steps = 6, 512, 64, 3
+G, B, K, steps = 6, 512, 64, 6
 g = torch.Generator(device="cuda").manual_seed(21)
 Xs = [torch.rand(B, G * 64, generator=g, device="cuda") for _ in range(steps)]
 Es = [torch.randn(1, B, K, generator=g, device="cuda") for _ in range(steps)]
@@ -74,8 +74,8 @@ t_prox = 7.5   # rows of Ws ~ N(0,1)^64 have norm ~8: a good third of them dies 
 
 def run(eng, rows, sync_on):
   scal = []
+  sync = parallel.BucketedGradSync(eng) if sync_on else None   # one object for all steps, as bench.py uses it
   for X, eps in zip(Xs, Es):
-    sync = parallel.BucketedGradSync(eng) if sync_on else None
     out = eng.forward_backward(X[rows].contiguous(), eps[:, rows].contiguous(), 1.0, lam=1.0, grad_sync=sync)
     sc = out["scalars"].clone()
     if sync_on:
