@@ -1,5 +1,5 @@
 set -e
-R=gpurun_out/r02b
+R=gpurun_out/${1:-r02c}
 mkdir -p $R
 ROOT=$(pwd)
 timeout -k 10 400 python3 bench.py > $R/bench_line.json 2> $R/bench.err
