@@ -355,6 +355,123 @@ __device__ __forceinline__ void h2_step(f32x16 (&acc)[NI][NJ], const u32x4 (&fa)
       for (int j = 0; j < NJ; ++j) acc[i][j] = mfma_f16(fa[i][PA[q]], fb[j][PB[q]], acc[i][j]);
 }
 
+// ------------------------------------------------------------------------------
+// Consumer wave of the h2 kernels on v_mfma_f32_16x16x32_f16.  On this power-limited chip the 16x16x32 shape delivers
+// 13 % more flops than 32x32x16 on random operands (tools/probe/mfma_shape_power.hip: 2006 against 1772 TFLOP/s).
+// A wave owns 64 x 64 outputs = 4 x 4 tiles of 16 x 16 (64 accumulator registers, as before); one macro tile of the
+// operands is one reduction step of 32.  Lane (l15 = lane & 15, kb = lane >> 4) holds row pi(l15) of a 16-row block and
+// the 8 reduction slots of chunk kb: chunks 0..3 are (sub-step image, half) = (0,0), (1,0), (0,1), (1,1), and pi
+// interleaves the rows so that every 16-lane group of a ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) meets
+// sixteen different 4-bank groups: rows with r mod 4 in {0,1} for lanes 0-3 and 12-15, {2,3} for lanes 4-11; the two
+// chunks a group mixes lie 4 bank groups apart (kH2Sub), which those two row sets are closed under.
+// Operand registers: rows halves A0, A1 and column halves B0, B1, 16 registers each (64, as before).  The four
+// quadrant products of a macro tile run in a cyclic order -- (0,0) (0,1) (1,1) (1,0) on even tiles, (0,1) (0,0) (1,0)
+// (1,1) on odd ones -- so that the last product of a tile, which is still to be issued when the tile's barrier comes,
+// leaves free exactly the two operand sets the next tile's first product needs.
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ int h2_pi16(int l) {
+  return l < 4 ? (l & 1) + 4 * (l >> 1) : l < 12 ? 2 + ((l - 4) & 1) + 4 * ((l - 4) >> 1) : 8 + ((l - 12) & 1) + 4 * ((l - 12) >> 1);
+}
+__device__ __forceinline__ f32x4 mfma16_f16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(x3_h16x8, a), __builtin_bit_cast(x3_h16x8, b), c, 0, 0, 0);
+}
+struct H2Consumer16 {
+  f32x4 acc[4][4];
+  u32x4 pa[2][2][2], pb[2][2][2];   // [half][16-row block][term]
+  const uint32_t* a0;
+  const uint32_t* b0;
+  __device__ __forceinline__ void init(const uint32_t* lds, int wm, int wn, int lane) {
+    const int l15 = lane & 15, kb = lane >> 4;
+    const int off = (kb & 1) * kH2Sub + 4 * (kb >> 1);
+    a0 = lds + (wm * 64 + h2_pi16(l15)) * kH2Row + off;
+    b0 = lds + 2 * kH2Sub + (wn * 64 + h2_pi16(l15)) * kH2Row + off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
+  }
+  template <int RH> __device__ __forceinline__ void rdA(int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) pa[RH][i][p] = *reinterpret_cast<const u32x4*>(a0 + buf * kH2Buf + (32 * RH + 16 * i) * kH2Row + 8 * p);
+  }
+  template <int CH> __device__ __forceinline__ void rdB(int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) pb[CH][i][p] = *reinterpret_cast<const u32x4*>(b0 + buf * kH2Buf + (32 * CH + 16 * i) * kH2Row + 8 * p);
+  }
+  template <int RH, int CH> __device__ __forceinline__ void mm() {
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};  // lo*hi, hi*lo, hi*hi
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[2 * RH + i][2 * CH + j] = mfma16_f16(pa[RH][i][PA[q]], pb[CH][j][PB[q]], acc[2 * RH + i][2 * CH + j]);
+  }
+  // all T macro tiles; every consumer passes barriers P_{-1} .. P_{Tr-1}
+  __device__ __forceinline__ void even_tile(int buf) {   // (0,0) (0,1) (1,1); (1,0) stays to be issued
+    rdA<0>(buf); rdB<0>(buf);
+    __builtin_amdgcn_sched_barrier(0);
+    mm<1, 1>();                       // the previous (odd) tile's last product (zero operands before the first tile)
+    __builtin_amdgcn_sched_barrier(0);
+    rdB<1>(buf);
+    __builtin_amdgcn_sched_barrier(0);
+    mm<0, 0>();
+    __builtin_amdgcn_sched_barrier(0);
+    rdA<1>(buf);
+    __builtin_amdgcn_sched_barrier(0);
+    mm<0, 1>();
+    __builtin_amdgcn_sched_barrier(0);
+    mm<1, 1>();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void odd_tile(int buf) {    // (0,1) (0,0) (1,0); (1,1) stays to be issued
+    rdA<0>(buf); rdB<1>(buf);
+    __builtin_amdgcn_sched_barrier(0);
+    mm<1, 0>();                       // the previous (even) tile's last product
+    __builtin_amdgcn_sched_barrier(0);
+    rdB<0>(buf);
+    __builtin_amdgcn_sched_barrier(0);
+    mm<0, 1>();
+    __builtin_amdgcn_sched_barrier(0);
+    rdA<1>(buf);
+    __builtin_amdgcn_sched_barrier(0);
+    mm<0, 0>();
+    __builtin_amdgcn_sched_barrier(0);
+    mm<1, 0>();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void run(int T, int Tr) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) { pa[1][i][p] = (u32x4)(0u); pb[1][i][p] = (u32x4)(0u); }
+    __syncthreads();  // P_{-1}
+    int t = 0;
+    for (; t + 1 < T; t += 2) {
+      even_tile(0);
+      __syncthreads();  // P_t
+      odd_tile(1);
+      __syncthreads();  // P_{t+1}
+    }
+    if (t < T) {
+      even_tile(0);
+      __syncthreads();
+      mm<1, 0>();
+    } else if (T > 0) {
+      mm<1, 1>();
+    }
+    for (int u = T; u < Tr; ++u) __syncthreads();
+  }
+  // output (16-row block I, 16-column block Jb, register i) of lane: tile row / tile column inside the wave's 64 x 64
+  __device__ __forceinline__ static int out_row(int I, int i, int lane) { return 16 * I + h2_pi16(4 * (lane >> 4) + i); }
+  __device__ __forceinline__ static int out_col(int Jb, int lane) { return 16 * Jb + h2_pi16(lane & 15); }
+};
+
 __global__ __launch_bounds__(768, 1) void enc_h2_bwd_gemm(const float* __restrict__ X, int64_t B, int D, int J,
                                                           const uint32_t* __restrict__ Pimg, int BT,
                                                           float* __restrict__ out0, float* __restrict__ out1,
@@ -364,7 +481,7 @@ __global__ __launch_bounds__(768, 1) void enc_h2_bwd_gemm(const float* __restric
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint32_t* lds = reinterpret_cast<uint32_t*>(smem_raw);  // [2][kH2Buf]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
+  const int lane = threadIdx.x & 63;
   const int64_t m0 = (int64_t)blockIdx.x * 128;  // first column d
   const int j0 = blockIdx.y * 128;
   const int T = (int)(B / 32);
@@ -452,50 +569,22 @@ __global__ __launch_bounds__(768, 1) void enc_h2_bwd_gemm(const float* __restric
       if (lane == 0) atomicMax(rng_seen, __float_as_uint(xmax));
     }
   } else {
-    // ---------------- consumers ----------------
+    // ---------------- consumers (H2Consumer16) ----------------
     const int wm = wave >> 1, wn = wave & 1;
-    const uint32_t* a0 = lds + (wm * 64 + l31) * kH2Row + 4 * hh;
-    const uint32_t* b0 = lds + 2 * kH2Sub + (wn * 64 + l31) * kH2Row + 4 * hh;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
-    u32x4 fa[2][2][2], fb[2][2][2];  // [sub-step][tile][piece]
-    auto lread = [&](int buf, int s) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          fa[s][i][p] = *reinterpret_cast<const u32x4*>(a0 + buf * kH2Buf + s * kH2Sub + 32 * i * kH2Row + 8 * p);
-          fb[s][i][p] = *reinterpret_cast<const u32x4*>(b0 + buf * kH2Buf + s * kH2Sub + 32 * i * kH2Row + 8 * p);
-        }
-    };
-    __syncthreads();  // P_{-1}
-    for (int t = 0; t < T; ++t) {
-      lread(t & 1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (t > 0) h2_step<2, 2>(acc, fa[1], fb[1]);
-      __builtin_amdgcn_sched_barrier(0);
-      lread(t & 1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      h2_step<2, 2>(acc, fa[0], fb[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();  // P_t
-    }
-    h2_step<2, 2>(acc, fa[1], fb[1]);
-    for (int t = T; t < Tr; ++t) __syncthreads();
+    H2Consumer16 cw;
+    cw.init(lds, wm, wn, lane);
+    cw.run(T, Tr);
     const int Kh = J / 2;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int I = 0; I < 4; ++I)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = j0 + (wn * 2 + j) * 32 + l31;
+      for (int Jb = 0; Jb < 4; ++Jb) {
+        const int col = j0 + wn * 64 + H2Consumer16::out_col(Jb, lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int mrow = (wm * 2 + i) * 32 + OIVAE_ROW(r, hh);
+        for (int i = 0; i < 4; ++i) {
+          const int mrow = wm * 64 + H2Consumer16::out_row(I, i, lane);
           const int64_t d = m0 + 4 * (mrow & 31) + (mrow >> 5);  // LDS row rho -> column of X
-          if (col < J) (col < Kh ? out0 + (int64_t)col * D : out1 + (int64_t)(col - Kh) * D)[d] = (acc[i][j][r] * ix) * ip;
+          if (col < J) (col < Kh ? out0 + (int64_t)col * D : out1 + (int64_t)(col - Kh) * D)[d] = (cw.acc[I][Jb][i] * ix) * ip;
         }
       }
   }
@@ -556,7 +645,7 @@ __global__ __launch_bounds__(768, 1) void enc_h2_fwd_gemm(const float* __restric
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint32_t* lds = reinterpret_cast<uint32_t*>(smem_raw);  // [2][kH2Buf]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
+  const int lane = threadIdx.x & 63;
   const int64_t m0 = (int64_t)blockIdx.x * 128;
   const int j0 = blockIdx.y * 128;
   const int kbeg = blockIdx.z * klen;
@@ -648,48 +737,20 @@ __global__ __launch_bounds__(768, 1) void enc_h2_fwd_gemm(const float* __restric
     for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o));
     if (lane == 0) atomicMax(rng, __float_as_uint(xmax));
   } else {
-    // ---------------- consumers ----------------
+    // ---------------- consumers (H2Consumer16) ----------------
     const int wm = wave >> 1, wn = wave & 1;
-    const uint32_t* a0 = lds + (wm * 64 + l31) * kH2Row + 4 * hh;
-    const uint32_t* b0 = lds + 2 * kH2Sub + (wn * 64 + l31) * kH2Row + 4 * hh;
-    f32x16 acc[2][2];
+    H2Consumer16 cw;
+    cw.init(lds, wm, wn, lane);
+    cw.run(T, Tr);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int I = 0; I < 4; ++I)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
-    u32x4 fa[2][2][2], fb[2][2][2];
-    auto lread = [&](int buf, int s) {
+      for (int Jb = 0; Jb < 4; ++Jb) {
+        const int col = j0 + wn * 64 + H2Consumer16::out_col(Jb, lane);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          fa[s][i][p] = *reinterpret_cast<const u32x4*>(a0 + buf * kH2Buf + s * kH2Sub + 32 * i * kH2Row + 8 * p);
-          fb[s][i][p] = *reinterpret_cast<const u32x4*>(b0 + buf * kH2Buf + s * kH2Sub + 32 * i * kH2Row + 8 * p);
-        }
-    };
-    __syncthreads();  // P_{-1}
-    for (int t = 0; t < T; ++t) {
-      lread(t & 1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (t > 0) h2_step<2, 2>(acc, fa[1], fb[1]);
-      __builtin_amdgcn_sched_barrier(0);
-      lread(t & 1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      h2_step<2, 2>(acc, fa[0], fb[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();  // P_t
-    }
-    h2_step<2, 2>(acc, fa[1], fb[1]);
-    for (int t = T; t < Tr; ++t) __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = j0 + (wn * 2 + j) * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = m0 + (wm * 2 + i) * 32 + OIVAE_ROW(r, hh);
-          if (row < B && col < J) pre[row * J + col] = (acc[i][j][r] * ix) * iw;
+        for (int i = 0; i < 4; ++i) {
+          const int64_t row = m0 + wm * 64 + H2Consumer16::out_row(I, i, lane);
+          if (row < B && col < J) pre[row * J + col] = (cw.acc[I][Jb][i] * ix) * iw;
         }
       }
   }
