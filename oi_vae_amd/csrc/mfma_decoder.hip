@@ -1696,6 +1696,20 @@ __device__ unsigned long long g_probe[8192 * 8];
 #define OIVAE_PROBE(i) do {} while (0)
 #endif
 
+// timing-only stand-in (tools/dec_ablate.py C16 / W16): the flops of one 32x32x16 product issued as two 16x16x32
+// instructions on the same operand registers (results are wrong)
+__device__ __forceinline__ void h2mm_as16(f32x16& acc, const Frag2& A, const Frag2& B) {
+  x3_f32x4 c0 = __builtin_shufflevector(acc, acc, 0, 1, 2, 3), c1 = __builtin_shufflevector(acc, acc, 4, 5, 6, 7);
+  constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(x3_h16x8, A.p[PA[q]]), __builtin_bit_cast(x3_h16x8, B.p[PB[q]]), c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(x3_h16x8, A.p[PA[q]]), __builtin_bit_cast(x3_h16x8, B.p[PB[q]]), c1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { acc[i] = c0[i]; acc[4 + i] = c1[i]; }
+}
+
 __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
   constexpr int K = 64, H = 64, M = 64, DG = 64, LW = 65;
   constexpr float kC = 2.885390081777927f;  // 2*log2(e): tanh(x) = 1 - 2/(exp2(kC x) + 1)
@@ -1915,6 +1929,8 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
       side(u);
 #ifdef OIVAE_ABL_NOCMFMA   // timing only: the chain wave without its matrix instructions
       acc[u >> 2][u & 15] += __uint_as_float((w[u % 3].p[0][0] ^ bf[u & 3].p[1][0] ^ w[u % 3].p[1][3] ^ bf[u & 3].p[0][3]) & 0x3fffffffu);
+#elif defined(OIVAE_ABL_C16)
+      h2mm_as16(acc[u >> 2], w[u % 3], bf[u & 3]);
 #else
       h2mm(acc[u >> 2], w[u % 3], bf[u & 3]);
 #endif
@@ -2193,6 +2209,9 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
           for (int e = 0; e < 4; ++e) { f.p[0][e] = __float_as_uint(v[8 * q + e]) & 0x3bff3bffu; f.p[1][e] = __float_as_uint(v[8 * q + 4 + e]) & 0x3bff3bffu; }
           return f;
         };
+#endif
+#ifdef OIVAE_ABL_W16
+        auto h2mm = [&](f32x16& acc, const Frag2& A, const Frag2& B) { h2mm_as16(acc, A, B); };
 #endif
 #ifdef OIVAE_ABL_NOWMFMA   // timing only: the weight-gradient wave without its matrix instructions
         auto h2mm = [&](f32x16& acc, const Frag2& A, const Frag2& B) {

@@ -7,6 +7,9 @@ cost compiled out (results of the scratch build are wrong by construction).
   python tools/dec_ablate.py [NOATOMIC ...]    # one child process per library
 
 Each child prints the decoder entry point's time at 65536 and 8192 rows.
+Tags (mfma_decoder.hip, OIVAE_ABL_<TAG>): NOATOMIC, NOCMFMA, NOWMFMA, NOCSPLIT, NOWSPLIT, NOPUB, NOTANH, NOX, CHAIN2, TIMES,
+C16 / W16 (the chain / weight-gradient wave's matrix flops issued as 16x16x32 instead of 32x32x16 instructions on the
+same operand registers: what the instruction shape alone is worth at the power limit).
 """
 import json
 import os
