@@ -959,15 +959,35 @@ __global__ __launch_bounds__(256) void dec_absmax_f32(const float* __restrict__ 
 //   [0..11]  (ks, term): transposed orientation, lane (row l31, half hh), slot e <-> latent x3_slot_feature(ks, hh, e)
 //   [12..23] (kb, q, term): plain orientation, lane (latent 32 kb + l31, half hh), slot e <-> row 16 q + 8 (e/4) + 4 hh + e%4
 // rows past N repeat row N-1 (the decoder zeroes their gradients).
+// lay16 (dec_x3_64s, 16x16x32 instructions; two fp16 terms only): lane (c = lane & 15, q = lane >> 4),
+//   [0..3]  (kk, nb): row 16 nb + c, slot e <-> latent 32 kk + 8 q + e
+//   [4..7]  kb: latent 16 kb + c, slot e <-> row 8 q + e
 __global__ __launch_bounds__(256) void x3_split_z(const float* __restrict__ z, int64_t N, uint32_t* __restrict__ img,
-                                                  const uint32_t* __restrict__ rng) {
+                                                  const uint32_t* __restrict__ rng, int lay16) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t tiles = (N + 31) / 32;
   if (i >= tiles * 512) return;
   const int64_t tile = i >> 9;
   const int grp = (int)(i >> 6) & 7, lane = (int)i & 63, l31 = lane & 31, hh = lane >> 5;
   float v[8];
-  if (grp < 4) {
+  if (lay16) {
+    const int lc = lane & 15, lq = lane >> 4;
+    if (grp < 4) {
+      int64_t n = tile * 32 + 16 * (grp & 1) + lc;
+      n = n < N ? n : N - 1;
+      const x3_f32x4 lo = *reinterpret_cast<const x3_f32x4*>(z + n * 64 + 32 * (grp >> 1) + 8 * lq);
+      const x3_f32x4 hi = *reinterpret_cast<const x3_f32x4*>(z + n * 64 + 32 * (grp >> 1) + 8 * lq + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int64_t n = tile * 32 + 8 * lq + e;
+        n = n < N ? n : N - 1;
+        v[e] = z[n * 64 + 16 * (grp - 4) + lc];
+      }
+    }
+  } else if (grp < 4) {
     int64_t n = tile * 32 + l31;
     n = n < N ? n : N - 1;
 #pragma unroll
@@ -2412,6 +2432,8 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
   OIVAE_PROBE(6);
 }
 
+#include "dec_x3_64s.h"
+
 // After a kernel that built its fp16 scales from rng[0] (the max|X| an earlier pass recorded) and recorded the
 // max|x| it read itself in rng[seen]: the result stands only if both maxima have the same power of two, i.e. if the
 // scales are the ones X's own maximum gives.  Otherwise flag rng[flag]: a gated second launch repeats the kernel with
@@ -2515,7 +2537,8 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   // (it also fetches the generator matrices 16 bytes per lane: parameters that are not 16-byte aligned take the bf16 pair)
   const bool aligned16 = ((reinterpret_cast<uintptr_t>(params->gen_W1) | reinterpret_cast<uintptr_t>(params->gen_W2) |
                            reinterpret_cast<uintptr_t>(params->Ws)) & 15) == 0;
-  const bool use_g = s.K == 64 && fits32 && aligned16 && (dec_env == nullptr || dec_env[0] == 'g');
+  const bool use_g = s.K == 64 && fits32 && aligned16 && (dec_env == nullptr || dec_env[0] == 'g' || dec_env[0] == 's');
+  const bool use_s = use_g && dec_env != nullptr && dec_env[0] == 's';   // the same kernel on 16x16x32 instructions
   uint32_t* rng = w.ranges;
   a.G = s.G;
   a.err = error_word_device();
@@ -2530,16 +2553,17 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
       OIVAE_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(x3_split_z, dim3((unsigned)((zt * 512 + 255) / 256)), dim3(256), 0, st, z, N, w.x3_z,
-                       use_g ? rng : (const uint32_t*)nullptr);
+                       use_g ? rng : (const uint32_t*)nullptr, use_s ? 1 : 0);
     OIVAE_LAUNCH_CHECK();
     a.zimg = w.x3_z;
     a.rng = rng;
     if (use_g) {
-      OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_x3_64g),
+      void (*const kern)(MfmaDecArgs) = use_s ? dec_x3_64s : dec_x3_64g;
+      OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
       const dim3 grid((unsigned)((s.G + 1) / 2), (unsigned)chunks);
       a.rng_seen = rng + 6;
-      hipLaunchKernelGGL(dec_x3_64g, grid, dim3(512), (size_t)kPairLds, st, a);
+      hipLaunchKernelGGL(kern, grid, dim3(512), (size_t)kPairLds, st, a);
       OIVAE_LAUNCH_CHECK();
       launch_range_guard(rng, 6, 7, st);
       OIVAE_LAUNCH_CHECK();
@@ -2549,7 +2573,7 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
       hipLaunchKernelGGL(gated_zero_f32, dim3((unsigned)zb), dim3(256), 0, st, dz, N * 64, (const uint32_t*)(rng + 7));
       a.rng_seen = nullptr;
       a.gate = rng + 7;
-      hipLaunchKernelGGL(dec_x3_64g, grid, dim3(512), (size_t)kPairLds, st, a);
+      hipLaunchKernelGGL(kern, grid, dim3(512), (size_t)kPairLds, st, a);
     } else if (use_pair) {
       OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_x3_64p),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kX3DecLdsP));

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""dec_x3_64 (OIVAE_DEC=x3), dec_x3_64p (OIVAE_DEC=p) and dec_x3_64g (OIVAE_DEC=g, the default) beside
+"""dec_x3_64 (OIVAE_DEC=x3), dec_x3_64p (OIVAE_DEC=p) and dec_x3_64g (OIVAE_DEC=g), dec_x3_64s (OIVAE_DEC=s) beside
 dec_mfma64_v4: agreement on a ragged small case, then time at the scale-up shape."""
 import os
 import sys
@@ -23,7 +23,7 @@ def agree():
   X = torch.rand(B, 24 * 64, generator=g, device="cuda")
   eps = torch.randn(S, B, 64, generator=g, device="cuda")
   res = {}
-  for m in ("v4", "x3", "p", "g"):
+  for m in ("v4", "x3", "p", "g", "s"):
     setmode(m)
     out = eng.forward_backward(X, eps, 0.7)
     torch.cuda.synchronize()
@@ -44,7 +44,7 @@ def timing():
   B = 65536
   X = torch.rand(B, 65536, generator=g, device="cuda")
   eps = torch.randn(1, B, 64, generator=g, device="cuda")
-  for m in ("x3", "p", "g", "p", "g"):
+  for m in ("g", "s", "g", "s"):
     setmode(m)
     eng.forward_backward(X, eps, 1.0)
     eng.trace = []
