@@ -28,9 +28,9 @@ GLOBAL_BATCH = 65536
 LR, WS_LR, LAM = 1e-3, 1e-4, 1.0
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 F16_MATRIX_PEAK_TFLOPS = 16 * 157.3  # dense fp16/bf16 MFMA = 16 x the fp32 matrix rate, same table (2516.8)
-# what the chip sustains on v_mfma_f32_32x32x16_{bf16,f16} alone with random operands (tools/probe/mfma_power.hip: the
-# clock falls from 2.37 to 1.79 GHz at the power limit; with all-zero operands the probe reaches 2445)
-F16_MATRIX_SUSTAINED_TFLOPS = 1852.0
+# what the chip sustains on v_mfma_f32_16x16x32_f16 alone with random operands at its power limit
+# (tools/probe/mfma_shape_power.hip: 2006 TFLOP/s; the 32x32x16 shape reaches 1772-1852, all-zero operands 2445)
+F16_MATRIX_SUSTAINED_TFLOPS = 2006.0
 PMC_FILE = os.path.join("profiles", "pmc_per_kernel_latest.json")
 
 
@@ -40,7 +40,7 @@ def pmc_traffic():
   the same kernel, not this run's."""
   try:
     d = json.load(open(os.path.join(ROOT, PMC_FILE)))
-    name, k = next((n, v) for n, v in sorted(d.items(), reverse=True) if "dec_x3_64g" in n)
+    name, k = next((n, v) for n, v in sorted(d.items(), reverse=True) if "dec_x3_64s" in n or "dec_x3_64g" in n)
     return {"bytes": k["hbm_read_bytes_corrected"] + k["hbm_write_bytes"], "read_bytes": k["hbm_read_bytes_corrected"],
             "write_bytes": k["hbm_write_bytes"], "kernel": name, "source": PMC_FILE}
   except Exception:
@@ -60,10 +60,10 @@ def decoder_executed_flops(rows):
 
 
 def decoder_f16_flops(rows):
-  """16-bit matrix flops dec_x3_64g issues in the row loop: each of the six fp32 products (2 x 2 blocks of 32 x 32,
-  four reduction steps of 16) as three fp16 products: 144 v_mfma_f32_32x32x16_f16 of 2*32*32*16 flops per 32-row
-  tile and group."""
-  return (rows + 31) // 32 * G * 144 * (2 * 32 * 32 * 16)
+  """16-bit matrix flops dec_x3_64s issues in the row loop: each of the six fp32 products (64 x 32 x 64 per 32-row tile:
+  eight 16 x 16 blocks, two reduction steps of 32) as three fp16 products: 288 v_mfma_f32_16x16x32_f16 of 2*16*16*32
+  flops per 32-row tile and group (dec_x3_64g issued the same flops as 144 32x32x16 instructions)."""
+  return (rows + 31) // 32 * G * 288 * (2 * 16 * 16 * 32)
 
 
 def encoder_flops_per_row():
@@ -282,8 +282,8 @@ def main():
       "config": {"workload": "synthetic scale-up: G=1024 groups x 64 dims, K=64, H=M=64 two-layer generators, "
                              "global batch 65536, S=1", "global_batch": GLOBAL_BATCH,
                  "parallelism": "dp%d" % world, "rows_per_gpu": rows},
-      # the dominant kernel against the pipe it runs on: v_mfma_f32_32x32x16_f16
-      "roofline": {"bound": "mfma", "kernel": "dec_x3_64g (grouped decoder fwd+bwd, fp32 products as 3 fp16 MFMAs)",
+      # the dominant kernel against the pipe it runs on: v_mfma_f32_16x16x32_f16
+      "roofline": {"bound": "mfma", "kernel": "dec_x3_64s (grouped decoder fwd+bwd, fp32 products as 3 fp16 MFMAs)",
                    "achieved": tf(f16), "peak": F16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": tf(f16) / F16_MATRIX_PEAK_TFLOPS,
                    "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
@@ -295,14 +295,14 @@ def main():
                    "fp32_equivalent": {"executed_flops_per_launch": exe, "executed_tflops": tf(exe),
                                        "algorithmic_over_fp32_matrix_peak": tf(alg) / FP32_MATRIX_PEAK_TFLOPS,
                                        "fp32_matrix_peak": FP32_MATRIX_PEAK_TFLOPS},
-                   "note": "achieved/frac: the 16-bit matrix flops the kernel ISSUES (144 v_mfma_f32_32x32x16_f16 per "
+                   "note": "achieved/frac: the 16-bit matrix flops the kernel ISSUES (288 v_mfma_f32_16x16x32_f16 per "
                            "32-row tile and group) over the dense fp16 peak; useful_frac: the reference algorithm's fp32 "
                            "flops (9 products per group, SURVEY 8d) over the same peak -- each fp32 product costs three "
                            "fp16 products, and W^(g) z composed with the generator's first Linear makes 6 of the 9; "
                            "frac_of_sustained: against what the power-limited chip reaches on that instruction alone "
                            "with random operands; fp32_equivalent: the same work priced on the fp32 matrix pipe the "
                            "kernel does not use (round 1's frac of 2.29).  avg_launch_ms is the decoder ENTRY POINT "
-                           "timed with HIP events on its stream: dec_x3_64g plus ~0.06 ms of helpers (max|z|, the "
+                           "timed with HIP events on its stream: dec_x3_64s plus ~0.06 ms of helpers (max|z|, the "
                            "image of z, the range guard and its gated second launch); profiles/ holds the "
                            "rocprofv3 kernel trace of the same command.  The kernel is not matrix-bound: the chain "
                            "wave's dependent sequence and the dz float atomics (8.6 GB per launch) bound it, DESIGN 3.0"},
@@ -311,7 +311,7 @@ def main():
       "extra": extras,
       "arithmetic": "fp32 in, fp32 out, fp32 accumulation everywhere.  Encoder GEMMs and decoder products: two fp16 "
                     "terms per operand after an exact power-of-two scaling by the operand's maximum (or a bound of "
-                    "it), three v_mfma_f32_32x32x16_f16 products per fp32 product (x3_split.h); every kernel that "
+                    "it), three v_mfma_f32_16x16x32_f16 products per fp32 product (x3_split.h); every kernel that "
                     "scales X checks the maximum it assumed against what it read and repeats itself otherwise.  "
                     "Error against float64 no larger than the fp32 matrix instructions' (tests/test_gpu_x3.py).  "
                     "extra.ms_per_step_bf16x3_exact_operands: OIVAE_ENC=bf16 OIVAE_DEC=p (operands carried exactly as "

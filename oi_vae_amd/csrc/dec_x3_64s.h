@@ -236,19 +236,43 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
   // requested and the operands of the second reduction step are split inside units 0 and 1.
   auto chain_mm = [&](f32x4 (*acc)[2], auto&& wf, Frag2* bf, auto&& make, auto&& side) {
     Frag2 w[3];
+#ifdef OIVAE_ABL_SFB   // experiment: feature block outer, reduction step inner (an accumulator is final after two units)
+    w[0] = wf(0, 0);
+    w[1] = wf(0, 1);
+    bf[0] = make(0);
+    bf[1] = make(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u + 2 < 8) w[(u + 2) % 3] = wf((u + 2) >> 1, (u + 2) & 1);
+      if (u == 0) { bf[2] = make(2); bf[3] = make(3); }
+      if (u >= 2) side((u - 2) >> 1, (u - 2) & 1);
+      h2mm16<2>(acc[u >> 1], w[u % 3], bf + 2 * (u & 1));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
     w[0] = wf(0, 0);
     w[1] = wf(1, 0);
     bf[0] = make(0);
+#ifdef OIVAE_ABL_SM1
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u + 2 < 8) w[(u + 2) % 3] = wf((u + 2) & 3, (u + 2) >> 2);
+      if (u < 3) bf[1 + u] = make(1 + u);
+#else
     bf[1] = make(1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (u + 2 < 8) w[(u + 2) % 3] = wf((u + 2) & 3, (u + 2) >> 2);
       if (u < 2) bf[2 + u] = make(2 + u);
-      side(u);
+#endif
+      if (u >= 5) { side(u - 5, 0); side(u - 5, 1); }
       h2mm16<2>(acc[u & 3], w[u % 3], bf + 2 * (u >> 2));
       __builtin_amdgcn_sched_barrier(0);
     }
+#endif
   };
   auto init_t = [&](f32x4 (*acc)[2], const float* v0) {
 #pragma unroll
@@ -266,6 +290,11 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
     return r;
   };
   constexpr int LT = 68;   // a chain wave's fp32 tile [32 rows][68]
+#ifdef OIVAE_ABL_SPK
+  constexpr bool kInsideScalar = false;
+#else
+  constexpr bool kInsideScalar = true;
+#endif
 
   const int N32 = (int)a.N;
   const int ntiles = (N32 + 31) / 32;
@@ -283,7 +312,11 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
   if (chainw) {
     // =============================== chain wave ===============================
     __builtin_amdgcn_s_setprio(3);
+#ifdef OIVAE_ABL_SNOSWZ
+    const int sx = 0;
+#else
     const int sx = (lc >> 3) & 1;   // rows 8..15 of a 16-row block store their 16-column blocks swapped
+#endif
     float* trw0 = scr + sw * kPairTile + lc * LT + 4 * lq + 16 * sx;        // even feature blocks
     float* trw1 = scr + sw * kPairTile + lc * LT + 4 * lq + 16 - 16 * sx;   // odd feature blocks
     auto tr_write = [&](const f32x4 (*v)[2]) {
@@ -346,7 +379,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
         // ---- a1 + b1 in units of 1 / (s1 sz) ----
         f32x4 uT[4][2];
         init_t(uT, sb1);
-        auto none = [&](int) {};
+        auto none = [&](int, int) {};
         chain_mm(uT, [&](int fb, int kk) { return wfrag(imgl, 0, fb, kk); }, zf, [&](int f) { return zf[f]; }, none);
         // ---- t = tanh: published first, split during the next product ----
         uint32_t peek = con_peek();
@@ -367,24 +400,20 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
         Frag2 tf[4];
         f32x4 gT[4][2];
         init_t(gT, sb2);
-        auto gmu_block = [&](int fb, bool inside) {
-          const f32x4 c3 = *reinterpret_cast<const f32x4*>(sC3 + 16 * fb + 4 * lq);   // - c3 in scaled units
+        auto gmu_block = [&](int fb, int nb, bool inside) {
+          f32x4 c3n = *reinterpret_cast<const f32x4*>(sC3 + 16 * fb + 4 * lq);   // - c3 in scaled units
+          if (partial) {   // rows past the end of the batch contribute nothing (a real, uniform branch: last tile only)
+            asm volatile("");
+            c3n *= liveT[nb];
+          }
+          const f32x4 x4 = xq[fb][nb];
+          asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(xm) : "v"(x4[0]), "v"(x4[1]));
+          asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(xm) : "v"(x4[2]), "v"(x4[3]));
+          if (inside) {   // inside the product: scalar instructions (packed ones between matrix instructions cost time)
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
-            f32x4 c3n = c3;
-            if (partial) {   // rows past the end of the batch contribute nothing (a real, uniform branch: last tile only)
-              asm volatile("");
-              c3n *= liveT[nb];
-            }
-            const f32x4 x4 = xq[fb][nb];
-            asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(xm) : "v"(x4[0]), "v"(x4[1]));
-            asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(xm) : "v"(x4[2]), "v"(x4[3]));
-            if (inside) {   // inside the product: scalar instructions (packed ones between matrix instructions cost time)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) gT[fb][nb][i] = fmaf(gT[fb][nb][i], k_ninv2, x4[i]) * c3n[i];
-            } else {
-              gT[fb][nb] = (gT[fb][nb] * k_ninv2 + x4) * c3n;   // (mu - x) c3 = (x - mu) (- c3)
-            }
+            for (int i = 0; i < 4; ++i) gT[fb][nb][i] = fmaf(gT[fb][nb][i], k_ninv2, x4[i]) * c3n[i];
+          } else {
+            gT[fb][nb] = (gT[fb][nb] * k_ninv2 + x4) * c3n;   // (mu - x) c3 = (x - mu) (- c3)
           }
         };
         chain_mm(gT, [&](int fb, int kk) { return wfrag(imgl, 1, fb, kk); }, tf,
@@ -398,9 +427,10 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
                        uT[2 * kk + j][nb][r] = fmaf(k_nomt2 * uT[2 * kk + j][nb][r], uT[2 * kk + j][nb][r], k_omtC);
                    return fr;
                  },
-                 [&](int u) { if (u >= 5) gmu_block(u - 5, true); });
+                 [&](int fb, int nb) { gmu_block(fb, nb, kInsideScalar); });
         peek = con_peek();
-        gmu_block(3, false);
+        gmu_block(3, 0, false);
+        gmu_block(3, 1, false);
         publish(gT, peek);
         // ---- dt = W2^T gmu; da1 = dt (1 - t^2) ----
         Frag2 gf[4];
@@ -409,13 +439,9 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
         for (int fb = 0; fb < 4; ++fb) { dT[fb][0] = (f32x4)(0.f); dT[fb][1] = (f32x4)(0.f); }
         chain_mm(dT, [&](int fb, int kk) { return wfrag(imgl, 2, fb, kk); }, gf,
                  [&](int f) { return split8_h2v(gT[2 * (f >> 1)][f & 1], gT[2 * (f >> 1) + 1][f & 1]); },
-                 [&](int u) {
-                   if (u >= 5) {
+                 [&](int fb, int nb) {
 #pragma unroll
-                     for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                       for (int r = 0; r < 4; ++r) dT[u - 5][nb][r] *= uT[u - 5][nb][r];
-                   }
+                   for (int r = 0; r < 4; ++r) dT[fb][nb][r] *= uT[fb][nb][r];
                  });
         peek = con_peek();
         dT[3][0] *= uT[3][0];
@@ -438,28 +464,24 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
         // dz^T[k][n] at dzT + k N + n: uniform row base (scalar registers) + 32-bit per-lane byte offset
         uint32_t voff0 = (uint32_t)((int64_t)(4 * lq) * a.N + nT0) * 4u, voff1 = (uint32_t)((int64_t)(4 * lq) * a.N + nT1) * 4u;
         asm volatile("" : "+v"(voff0), "+v"(voff1));
-        auto dz_adds = [&](int fb, bool scalar_mul) {
-          f32x4 o0 = dz[fb][0], o1 = dz[fb][1];
+        auto dz_adds = [&](int fb, int nb, bool scalar_mul) {
+          f32x4 o = dz[fb][nb];
           if (scalar_mul) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { o0[r] *= k_inv4; o1[r] *= k_inv4; }
+            for (int r = 0; r < 4; ++r) o[r] *= k_inv4;
           } else {
-            o0 *= k_inv4;
-            o1 *= k_inv4;
+            o *= k_inv4;
           }
-          if (live0) {
+          if (nb ? live1 : live0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) OIVAE_DZ_ADD(reinterpret_cast<float*>(dzb + (int64_t)(16 * fb + r) * rowbytes + voff0), o0[r]);
-          }
-          if (live1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) OIVAE_DZ_ADD(reinterpret_cast<float*>(dzb + (int64_t)(16 * fb + r) * rowbytes + voff1), o1[r]);
+            for (int r = 0; r < 4; ++r)
+              OIVAE_DZ_ADD(reinterpret_cast<float*>(dzb + (int64_t)(16 * fb + r) * rowbytes + (nb ? voff1 : voff0)), o[r]);
           }
         };
         chain_mm(dz, [&](int kb, int kk) { return wfrag_tr(trb, kb, kk); }, df,
                  [&](int f) { return split8_h2v(dT[2 * (f >> 1)][f & 1], dT[2 * (f >> 1) + 1][f & 1]); },
-                 [&](int u) { if (u >= 5 && last) dz_adds(u - 5, true); });
-        if (last) dz_adds(3, false);
+                 [&](int fb, int nb) { if (last) dz_adds(fb, nb, kInsideScalar); });
+        if (last) { dz_adds(3, 0, false); dz_adds(3, 1, false); }
       }
     }
   } else if (active) {
@@ -467,7 +489,11 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
     // producer j = 0: chain wave 2 wp + wgrp (this group is the first half of its row tile), j = 1: the other one
     uint32_t seen[2] = {0, 0};
     const int npub = 3 * ngrp;
+#ifdef OIVAE_ABL_SNOSWZ
+    const int sr = 0;
+#else
     const int sr = lq & 1;   // rows 8 q + e: their 16-column blocks are swapped for odd q
+#endif
     for (int t0 = chunk * 4 + 2 * wp; t0 < ntiles; t0 += 4 * nchunks) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {

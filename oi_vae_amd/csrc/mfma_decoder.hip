@@ -2523,12 +2523,13 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   // test hooks: OIVAE_DEC=v1 the layer-by-layer fp32 template kernel (which also serves launches whose dz image
   // exceeds the 32-bit byte offsets of dec_mfma64_v4's atomics, N*K*4 >= 2^32), OIVAE_DEC=v4 the fp32
   // composed-first-layer kernel, OIVAE_DEC=x3 the single-wave-per-SIMD split-bf16 kernel, OIVAE_DEC=p the all-bf16
-  // pair of waves, OIVAE_DEC=g (= unset) the default below
+  // pair of waves, OIVAE_DEC=g dec_x3_64g (32x32x16 fp16 instructions; round 2's default until dec_x3_64s), OIVAE_DEC=s
+  // (= unset) dec_x3_64s, the default below
   const bool force_v1 = dec_env != nullptr && dec_env[0] == 'v' && dec_env[1] == '1';
   const bool use_x3 = (dec_env != nullptr && (dec_env[0] == 'x' || dec_env[0] == 'p')) ||
                       (dec_env == nullptr && N * (int64_t)s.K * 4 >= ((int64_t)1 << 32));
   const bool use_pair = (dec_env != nullptr && dec_env[0] == 'p') || (dec_env == nullptr && N * (int64_t)s.K * 4 >= ((int64_t)1 << 32));
-  // default for the all-64 shape: dec_x3_64g (two groups per workgroup on fp16 terms); its scales assume the max|X|
+  // default for the all-64 shape: dec_x3_64s / dec_x3_64g (two groups per workgroup on fp16 terms); its scales assume the max|X|
   // that the workspace's ranges hold from the last pass over X (the forward encoder call of this step, or the
   // previous decoder call) and it checks that assumption against what it reads (range_guard): no host-side memory
   // of earlier calls.
@@ -2538,7 +2539,7 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   const bool aligned16 = ((reinterpret_cast<uintptr_t>(params->gen_W1) | reinterpret_cast<uintptr_t>(params->gen_W2) |
                            reinterpret_cast<uintptr_t>(params->Ws)) & 15) == 0;
   const bool use_g = s.K == 64 && fits32 && aligned16 && (dec_env == nullptr || dec_env[0] == 'g' || dec_env[0] == 's');
-  const bool use_s = use_g && dec_env != nullptr && dec_env[0] == 's';   // the same kernel on 16x16x32 instructions
+  const bool use_s = use_g && (dec_env == nullptr || dec_env[0] == 's');   // dec_x3_64s: the same kernel on 16x16x32 instructions (default)
   uint32_t* rng = w.ranges;
   a.G = s.G;
   a.err = error_word_device();

@@ -138,8 +138,8 @@ def test_x3_path_is_deterministic():
 
 
 def test_decoder_gradients_are_fp32_grade():
-  """oivae_decoder_fwd_bwd_f32 at the all-64 generator shape (dec_x3_64p by default, dec_x3_64 under OIVAE_DEC=x3, dec_mfma64_v4 under
-  OIVAE_DEC=v4)
+  """oivae_decoder_fwd_bwd_f32 at the all-64 generator shape (dec_x3_64s by default, dec_x3_64g under OIVAE_DEC=g, dec_x3_64 under
+  OIVAE_DEC=x3, dec_mfma64_v4 under OIVAE_DEC=v4)
   against float64 autograd of -loglik / (S B) on the same fp32 inputs: ragged row count, two samples per row."""
   from oi_vae_amd import Engine, ModelSpec, _lib
   G, K, B, S = 6, 64, 150, 2
@@ -169,7 +169,7 @@ def test_decoder_gradients_are_fp32_grade():
   want_dz = z64.grad.cpu()
 
   err = {}
-  for mode in ("v4", "x3", "default"):
+  for mode in ("v4", "x3", "g", "default"):
     _hooks(OIVAE_DEC=None if mode == "default" else mode)
     eng._ws_key = None
     ws = eng._workspace(B, S)
@@ -184,7 +184,7 @@ def test_decoder_gradients_are_fp32_grade():
       e[n] = float((got - want[n]).abs().max() / want[n].abs().max())
     err[mode] = e
   _hooks(OIVAE_DEC=None)
-  for mode in ("x3", "default"):
+  for mode in ("x3", "g", "default"):
     for n in err[mode]:
       assert err[mode][n] <= 5e-6, (mode, n, err)
       assert err[mode][n] <= 1.5 * err["v4"][n] + 3e-7, (mode, n, err)
@@ -192,7 +192,7 @@ def test_decoder_gradients_are_fp32_grade():
 
 @pytest.mark.parametrize("B,S", [(1, 1), (5, 1), (33, 3), (64, 1), (97, 2)])
 def test_paired_decoder_tiny_batches(B, S):
-  """dec_x3_64p at batches that leave tile streams empty (fewer than four 32-row tiles), end in a ragged tile or
+  """dec_x3_64s (default) and dec_x3_64g at batches that leave tile streams empty (fewer than four 32-row tiles), end in a ragged tile or
   repeat rows over samples: same scalars and gradients as the fp32-instruction kernel dec_mfma64_v4."""
   from tests.test_gpu_scale import _engine
   G = 5
@@ -201,21 +201,22 @@ def test_paired_decoder_tiny_batches(B, S):
   X = torch.rand(B, G * 64, generator=g, device="cuda")
   eps = torch.randn(S, B, 64, generator=g, device="cuda")
   res = {}
-  for mode in ("v4", None):
+  for mode in ("v4", "g", None):
     _hooks(OIVAE_DEC=mode)
     eng._ws_key = None
     out = eng.forward_backward(X, eps, 0.9)
     torch.cuda.synchronize()
     res[mode] = (eng.flat_grads.double().cpu().clone(), out["scalars"].double().cpu().clone())
   _hooks(OIVAE_DEC=None)
-  a, b = res[None], res["v4"]
-  assert torch.isfinite(a[0]).all()
-  assert float(((a[1][:6] - b[1][:6]).abs() / b[1][:6].abs().clamp(min=1.0)).max()) < 1e-5
-  for name in eng.seg_off:
-    o, n = eng.seg_off[name], eng.seg_numel[name]
-    if n:
-      ga, gb = a[0][o:o + n], b[0][o:o + n]
-      assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-12, name
+  for mode in (None, "g"):
+    a, b = res[mode], res["v4"]
+    assert torch.isfinite(a[0]).all()
+    assert float(((a[1][:6] - b[1][:6]).abs() / b[1][:6].abs().clamp(min=1.0)).max()) < 1e-5
+    for name in eng.seg_off:
+      o, n = eng.seg_off[name], eng.seg_numel[name]
+      if n:
+        ga, gb = a[0][o:o + n], b[0][o:o + n]
+        assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-12, (mode, name)
 
 
 def test_fp16_forward_depends_on_its_inputs_only():

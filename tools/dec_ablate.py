@@ -23,7 +23,7 @@ def child(tag):
   sys.path.insert(0, ROOT)
   import torch
   from oi_vae_amd import _lib
-  if tag != "shipped":
+  if tag != "shipped" and not tag.startswith("shipped"):
     _lib.LIB_PATH = os.path.join(ROOT, "tools", "probe", "liboivae_abl_%s.so" % tag)
   import bench
   dev = torch.device("cuda", 0)
