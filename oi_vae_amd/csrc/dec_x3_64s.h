@@ -22,6 +22,12 @@
 //     are swapped in rows 8..15 and 24..31 (column ^ 16) so that those reads meet 32 different banks per half wave
 //     while the chain wave's 16-byte stores stay conflict-free.  dW2 and P partials: acc[db][mb] of four registers
 //     (row 16 db + 4 q + i, column 16 mb + c), 128 persistent registers as before.
+//     (Tried and dropped: handing over the chain wave's fp16 FRAGMENTS instead of the fp32 tile, read transposed by the
+//     weight-gradient wave, which then neither splits nor reads fp32 and sums columns with v_dot2_f32_f16: correct,
+//     11.31 against 11.09 ms -- the fragment stores tie the chain wave's splits to its LDS queue, and the
+//     weight-gradient wave's vector work was never the bound.  Also measured against this form, all within 0.2 ms and
+//     none faster: feature block outer / reduction step inner units, no tile swizzle, packed fp32 side work inside
+//     products, one operand fragment split ahead of a product instead of two.)
 //   z image (x3_split_z, lay16): per 32-row tile fragments [0..3] = (kk, nb) in the chain's orientation,
 //     [4..7] = latent block kb in the weight-gradient orientation (lane = latent 16 kb + c, slots = rows 8 q + e).
 //   dz adds: one instruction covers 4 latent rows x 16 consecutive batch rows (64-byte runs); the chip-wide rate of
@@ -236,43 +242,19 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
   // requested and the operands of the second reduction step are split inside units 0 and 1.
   auto chain_mm = [&](f32x4 (*acc)[2], auto&& wf, Frag2* bf, auto&& make, auto&& side) {
     Frag2 w[3];
-#ifdef OIVAE_ABL_SFB   // experiment: feature block outer, reduction step inner (an accumulator is final after two units)
-    w[0] = wf(0, 0);
-    w[1] = wf(0, 1);
-    bf[0] = make(0);
-    bf[1] = make(1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (u + 2 < 8) w[(u + 2) % 3] = wf((u + 2) >> 1, (u + 2) & 1);
-      if (u == 0) { bf[2] = make(2); bf[3] = make(3); }
-      if (u >= 2) side((u - 2) >> 1, (u - 2) & 1);
-      h2mm16<2>(acc[u >> 1], w[u % 3], bf + 2 * (u & 1));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#else
     w[0] = wf(0, 0);
     w[1] = wf(1, 0);
     bf[0] = make(0);
-#ifdef OIVAE_ABL_SM1
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (u + 2 < 8) w[(u + 2) % 3] = wf((u + 2) & 3, (u + 2) >> 2);
-      if (u < 3) bf[1 + u] = make(1 + u);
-#else
     bf[1] = make(1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (u + 2 < 8) w[(u + 2) % 3] = wf((u + 2) & 3, (u + 2) >> 2);
       if (u < 2) bf[2 + u] = make(2 + u);
-#endif
       if (u >= 5) { side(u - 5, 0); side(u - 5, 1); }
       h2mm16<2>(acc[u & 3], w[u % 3], bf + 2 * (u >> 2));
       __builtin_amdgcn_sched_barrier(0);
     }
-#endif
   };
   auto init_t = [&](f32x4 (*acc)[2], const float* v0) {
 #pragma unroll
@@ -290,11 +272,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
     return r;
   };
   constexpr int LT = 68;   // a chain wave's fp32 tile [32 rows][68]
-#ifdef OIVAE_ABL_SPK
-  constexpr bool kInsideScalar = false;
-#else
-  constexpr bool kInsideScalar = true;
-#endif
+  constexpr bool kInsideScalar = true;   // side work between a product's matrix instructions: scalar fp32 (packed forms cost time there)
 
   const int N32 = (int)a.N;
   const int ntiles = (N32 + 31) / 32;
@@ -312,11 +290,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
   if (chainw) {
     // =============================== chain wave ===============================
     __builtin_amdgcn_s_setprio(3);
-#ifdef OIVAE_ABL_SNOSWZ
-    const int sx = 0;
-#else
     const int sx = (lc >> 3) & 1;   // rows 8..15 of a 16-row block store their 16-column blocks swapped
-#endif
     float* trw0 = scr + sw * kPairTile + lc * LT + 4 * lq + 16 * sx;        // even feature blocks
     float* trw1 = scr + sw * kPairTile + lc * LT + 4 * lq + 16 - 16 * sx;   // odd feature blocks
     auto tr_write = [&](const f32x4 (*v)[2]) {
@@ -489,11 +463,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
     // producer j = 0: chain wave 2 wp + wgrp (this group is the first half of its row tile), j = 1: the other one
     uint32_t seen[2] = {0, 0};
     const int npub = 3 * ngrp;
-#ifdef OIVAE_ABL_SNOSWZ
-    const int sr = 0;
-#else
     const int sr = lq & 1;   // rows 8 q + e: their 16-column blocks are swapped for odd q
-#endif
     for (int t0 = chunk * 4 + 2 * wp; t0 < ntiles; t0 += 4 * nchunks) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
