@@ -57,6 +57,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
   constexpr float kC = 2.885390081777927f;  // 2*log2(e): tanh(x) = 1 - 2/(exp2(kC x) + 1)
   constexpr float kSt = 8192.0f;            // t lies in (-1, 1)
   if (a.gate != nullptr && *a.gate == 0) return;
+  OIVAE_PROBE(0);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint32_t* img = reinterpret_cast<uint32_t*>(smem_raw);
   float* vec = reinterpret_cast<float*>(img + kPairImg);
@@ -212,8 +213,10 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
           *reinterpret_cast<x3_u32x4*>(img + (q * 3 + w) * 4096 + ((((r >> 4) * 2 + kk) * 2 + p) * 64 + iq * 16 + (r & 15)) * 4) = f.p[p];
       }
     }
+    OIVAE_PROBE(1 + q);
   }
   __syncthreads();
+  OIVAE_PROBE(3);
   // fragment (16-row block fb, step kk, term p) of image `which`: 1 KB, lane-major
   auto wfrag = [&](const uint32_t* imgl, int which, int fb, int kk) {
     Frag2 f;
@@ -286,6 +289,20 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
   float xm = 0.f;
   const int wgrp = sw & 1, wp = sw >> 1;   // weight-gradient wave (wp, wgrp): group wgrp of chain waves 2 wp, 2 wp + 1
   const bool active = chainw || wgrp < ngrp;
+  // Rounds of four row tiles (one per chain wave).  Every workgroup walks them from its own starting round, so that
+  // the workgroups running at one time add to different rows of dz: at a small batch (an 8-GPU shard) they otherwise
+  // stay in step and their float atomics meet on the same lines.
+  const int nrounds = (ntiles + 4 * nchunks - 1) / (4 * nchunks);
+  // (tools/dec_ablate.py on one box, decoder ms at 65536 / 8192 rows: no rotation 11.08 / 1.670, window of 8 rounds
+  // 11.11 / 1.669, 32 rounds 11.08 / 1.542, 128 rounds 11.24 / 1.553, all rounds 11.58 / 1.538: a wide window loses the
+  // L2 hits on z's image, which every workgroup reads)
+  constexpr int kRotW = 32;
+  const int rot = pairIdx % (nrounds < kRotW ? nrounds : kRotW);
+  auto tile_of = [&](int rnd, int c) {
+    int pr = rnd + rot;
+    if (pr >= nrounds) pr -= nrounds;
+    return (pr * nchunks + chunk) * 4 + c;
+  };
 
   if (chainw) {
     // =============================== chain wave ===============================
@@ -317,12 +334,19 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
     char* const dzb = reinterpret_cast<char*>(a.dzT);
     const int64_t rowbytes = a.N * 4;
     Frag2 zf[4];
-    if (chunk * 4 + sw < ntiles) {
+    {
+      int t1 = tile_of(0, sw);
+      if (t1 >= ntiles) t1 = tile_of(1, sw);   // (at most one round of a wave is past the end)
+      if (t1 < ntiles) {
 #pragma unroll
-      for (int f = 0; f < 4; ++f) zf[f] = zfrag2_of(chunk * 4 + sw, f);
+        for (int f = 0; f < 4; ++f) zf[f] = zfrag2_of(t1, f);
+      }
     }
-    for (int tile = chunk * 4 + sw; tile < ntiles; tile += 4 * nchunks) {
-      const int tnext = (tile + 4 * nchunks < ntiles) ? tile + 4 * nchunks : tile;
+    for (int rnd = 0; rnd < nrounds; ++rnd) {
+      const int tile = tile_of(rnd, sw);
+      if (tile >= ntiles) continue;
+      int tnext = rnd + 1 < nrounds ? tile_of(rnd + 1, sw) : tile;
+      if (tnext >= ntiles) tnext = rnd + 2 < nrounds ? tile_of(rnd + 2, sw) : tile;
       const int r0 = tile * 32;
       const bool partial = r0 + 32 > N32;
       const bool live0 = r0 + lc < N32, live1 = r0 + 16 + lc < N32;
@@ -464,11 +488,11 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
     uint32_t seen[2] = {0, 0};
     const int npub = 3 * ngrp;
     const int sr = lq & 1;   // rows 8 q + e: their 16-column blocks are swapped for odd q
-    for (int t0 = chunk * 4 + 2 * wp; t0 < ntiles; t0 += 4 * nchunks) {
+    for (int rnd = 0; rnd < nrounds; ++rnd) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int c = 2 * wp + (j ^ wgrp);           // the chain wave
-        const int tile = t0 - 2 * wp + c;             // its row tile of this round
+        const int tile = tile_of(rnd, c);             // its row tile of this round
         if (tile >= ntiles) continue;
         const float* trr0 = scr + c * kPairTile + 8 * lq * LT + lc + 16 * sr;
         const float* trr1 = scr + c * kPairTile + 8 * lq * LT + lc + 16 - 16 * sr;
@@ -537,7 +561,9 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
     }
   }
   // ---- end of the kernel (dec_x3_64g's, up to the accumulators' layout) ----
+  OIVAE_PROBE(4);
   __syncthreads();
+  OIVAE_PROBE(5);
   if (chainw) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) xm = fmaxf(xm, __shfl_xor(xm, o));
@@ -652,4 +678,5 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
       if (wtid == 0) a.ll_part[(int64_t)chunk * a.G + gq] = tot;
     }
   }
+  OIVAE_PROBE(6);
 }
