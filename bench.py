@@ -205,9 +205,16 @@ def main():
     eng.forward_backward(Xs, eps, 1.0, lam=LAM, grad_sync=sync)
     eng.trace = None
     if sync is not None:
-      sync.wait()  # both gradient buckets averaged over ranks before Adam / SGD / prox
-    eng.adam_step(LR)
-    eng.sgd_prox_step(WS_LR, t_prox)
+      # every bucket is averaged over ranks before ITS optimizers run: the decoder-side bucket (reduced under the
+      # encoder backward GEMM) first, so that its Adam, SGD and prox run under the encoder bucket's all-reduce
+      sync.wait_decoder()
+      eng.adam_step(LR, part="dec")
+      eng.sgd_prox_step(WS_LR, t_prox)
+      sync.wait_encoder()
+      eng.adam_step(LR, part="enc")
+    else:
+      eng.adam_step(LR)
+      eng.sgd_prox_step(WS_LR, t_prox)
 
   def barrier():
     if world > 1:

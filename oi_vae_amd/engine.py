@@ -319,15 +319,24 @@ class Engine:
                                              self.zero_mask.data_ptr(), self.row_norms.data_ptr(), self._stream()),
                  "oivae_sgd_prox_f32")
 
-  def adam_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
-    """torch.optim.Adam (default options) over every non-Ws parameter, one kernel."""
+  def adam_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0, part=None):
+    """torch.optim.Adam (default options) over every non-Ws parameter, one kernel.  ``part`` splits the update along
+    the data-parallel buckets (Adam is elementwise: the two halves give the bits of the whole): "dec" -- generators
+    and log_sigma, FIRST, it opens the step -- then "enc" -- the encoder, once its gradients are reduced."""
     n = self.adam_numel
     if self.adam_m is None:
       self.adam_m = torch.zeros(n, dtype=torch.float32, device=self.device)
       self.adam_v = torch.zeros(n, dtype=torch.float32, device=self.device)
-    self.adam_t += 1
+    cut = self.seg_off["gen_W1"]
+    if part not in (None, "dec", "enc"):
+      raise ValueError("part must be None, 'dec' or 'enc'")
+    if part != "enc":
+      self.adam_t += 1
+    lo, hi = (0, n) if part is None else ((cut, n) if part == "dec" else (0, cut))
+    if hi <= lo:
+      return
     with torch.cuda.device(self.device):
-      _lib.check(self.lib.oivae_adam_f32(self.flat_params.data_ptr(), self.flat_grads.data_ptr(),
-                                         self.adam_m.data_ptr(), self.adam_v.data_ptr(), n, float(lr),
+      _lib.check(self.lib.oivae_adam_f32(self.flat_params.data_ptr() + 4 * lo, self.flat_grads.data_ptr() + 4 * lo,
+                                         self.adam_m.data_ptr() + 4 * lo, self.adam_v.data_ptr() + 4 * lo, hi - lo, float(lr),
                                          float(betas[0]), float(betas[1]), float(eps), self.adam_t,
                                          float(grad_scale), self._stream()), "oivae_adam_f32")

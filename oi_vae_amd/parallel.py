@@ -52,7 +52,9 @@ class BucketedGradSync:
   all-reduce (60 % of the bytes at the scale-up shape) is issued right after it and
   runs on the communicator's stream while the encoder backward GEMM computes; the
   encoder part follows.  `wait()` makes the compute stream wait for both and must
-  be called before the optimizers and the proximal step.
+  be called before the optimizers and the proximal step (SURVEY.md section 8e);
+  `wait_decoder()` / `wait_encoder()` wait for one bucket each, so that the decoder-side
+  optimizers run under the encoder bucket's all-reduce (bench.py).
   Collectives are issued in the same order on every rank.  `holder` is anything
   with `flat_grads` and `seg_off` (an Engine)."""
 
@@ -68,9 +70,10 @@ class BucketedGradSync:
     backend = dist.get_backend(group) if (dist.is_available() and dist.is_initialized()) else ""
     # RCCL averages in the collective; gloo has no AVG, so sum and scale once in wait()
     self._avg = backend == "nccl"
-    self._pending = []
+    self._pending = {"dec": [], "enc": []}
+    self._unscaled = {"dec": False, "enc": False}
 
-  def _issue(self, t):
+  def _issue(self, t, which):
     if not self.active or t.numel() == 0:
       return
     op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
@@ -81,21 +84,34 @@ class BucketedGradSync:
       # and run the collective to its end before the next kernel is launched
       torch.cuda.synchronize(t.device)
       dist.all_reduce(t, op=op, group=self.group)
-      self._scale_pending = True
+      self._unscaled[which] = True
       return
-    self._pending.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
+    self._pending[which].append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
+    if not self._avg:
+      self._unscaled[which] = True
 
   def decoder_grads_ready(self):
-    self._issue(self.dec)
+    self._issue(self.dec, "dec")
 
   def encoder_grads_ready(self):
-    self._issue(self.enc)
+    self._issue(self.enc, "enc")
+
+  def _wait(self, which):
+    for w in self._pending[which]:
+      w.wait()
+    self._pending[which] = []
+    if self._unscaled[which]:
+      (self.dec if which == "dec" else self.enc).mul_(1.0 / self.world)
+      self._unscaled[which] = False
+
+  def wait_decoder(self):
+    """The compute stream waits for the decoder-side bucket only: the optimizers of the generators, log_sigma and Ws
+    (Engine.adam_step(part="dec"), sgd_prox_step) can then run while the encoder bucket is still being reduced."""
+    self._wait("dec")
+
+  def wait_encoder(self):
+    self._wait("enc")
 
   def wait(self):
-    for w in self._pending:
-      w.wait()
-    had = bool(self._pending) or getattr(self, "_scale_pending", False)
-    self._pending = []
-    self._scale_pending = False
-    if had and not self._avg:
-      self.flat.mul_(1.0 / self.world)
+    self._wait("dec")
+    self._wait("enc")

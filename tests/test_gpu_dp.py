@@ -78,11 +78,16 @@ def run(eng, rows, sync_on):
   for X, eps in zip(Xs, Es):
     out = eng.forward_backward(X[rows].contiguous(), eps[:, rows].contiguous(), 1.0, lam=1.0, grad_sync=sync)
     sc = out["scalars"].clone()
-    if sync_on:
-      sync.wait()
+    if sync_on:   # per-bucket optimizers, as bench.py runs them: the decoder side under the encoder bucket's all-reduce
+      sync.wait_decoder()
+      eng.adam_step(1e-3, part="dec")
+      eng.sgd_prox_step(1e-3, t_prox)
+      sync.wait_encoder()
+      eng.adam_step(1e-3, part="enc")
       parallel.reduce_scalars_(sc)
-    eng.adam_step(1e-3)
-    eng.sgd_prox_step(1e-3, t_prox)
+    else:         # one Adam launch over everything: the split form must give the same bits
+      eng.adam_step(1e-3)
+      eng.sgd_prox_step(1e-3, t_prox)
     scal.append(sc[:6].double().cpu())
   torch.cuda.synchronize()
   return torch.stack(scal)
@@ -132,3 +137,23 @@ def test_two_ranks_on_one_gpu_match_the_single_rank_step(tmp_path):
       o, _ = p.communicate()
     outs.append(o)
   assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+@pytest.mark.gpu
+def test_adam_in_two_parts_gives_the_bits_of_one_launch():
+  """Engine.adam_step(part="dec") then (part="enc") -- the per-bucket form of the data-parallel step -- against one
+  launch over every Adam parameter, three steps with moving gradients."""
+  import torch
+  from tests.test_gpu_scale import _engine
+  a, b = _engine(3, 64, 64, 64, 64, seed=8), _engine(3, 64, 64, 64, 64, seed=8)
+  g = torch.Generator(device="cuda").manual_seed(4)
+  for _ in range(3):
+    grads = torch.randn(a.flat_grads.shape, generator=g, device="cuda")
+    a.flat_grads.copy_(grads); b.flat_grads.copy_(grads)
+    a.adam_step(1e-2)
+    b.adam_step(1e-2, part="dec")
+    b.adam_step(1e-2, part="enc")
+  torch.cuda.synchronize()
+  assert a.adam_t == b.adam_t == 3
+  assert torch.equal(a.flat_params, b.flat_params)
+  assert torch.equal(a.adam_m, b.adam_m) and torch.equal(a.adam_v, b.adam_v)

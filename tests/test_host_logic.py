@@ -144,6 +144,13 @@ sync.decoder_grads_ready(); sync.encoder_grads_ready(); sync.wait()
 assert torch.equal(h.flat_grads, g), float((h.flat_grads - g).abs().max())
 sync.wait()  # idempotent once drained
 assert torch.equal(h.flat_grads, g)
+# ... and so must the per-bucket waits (bench.py: the decoder side's optimizers run between them)
+h.flat_grads.copy_(torch.from_numpy(g_local))
+sync.decoder_grads_ready(); sync.encoder_grads_ready()
+sync.wait_decoder()
+assert torch.equal(h.flat_grads[1000:], g[1000:])
+sync.wait_encoder()
+assert torch.equal(h.flat_grads, g)
 dist.destroy_process_group()
 print("rank", rank, "ok", err, serr)
 '''
