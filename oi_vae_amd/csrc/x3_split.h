@@ -80,6 +80,9 @@ __device__ __forceinline__ Split2 split2_pair(float a, float b) {   // a, b alre
 // a multiplication the compiler can fuse: a - float(h) is written as a * one - float(h) with a 1.0 the compiler cannot
 // see through, which is one v_fma_mix_f32 (fp16 operand converted on the fly) instead of a conversion and a
 // subtraction, and as exact.  (The decoder's chain wave is bound by its vector instructions: -1 ms per launch.)
+// (Tried: the low term written element by element, which the compiler turns into v_fma_mixlo_f16 / v_fma_mixhi_f16 --
+// three instructions per pair, same bits, 168 fewer vector instructions in dec_x3_64s: 11.48 against 11.34 ms on one
+// box, SLOWER -- the second one waits for the first one's partial write of the same register.)
 __device__ __forceinline__ Split2 split2_pair_mix(float a, float b) {
   Split2 r;
   const x3_h16x2 h = __builtin_convertvector(x3_f32x2{a, b}, x3_h16x2);
