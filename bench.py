@@ -194,6 +194,7 @@ def main():
   events = []
   sync = parallel.BucketedGradSync(eng) if world > 1 else None
   counter = [0]
+  comm_marks = []
 
   def step(timed, xs=None):
     xs = batches if xs is None else xs
@@ -207,10 +208,19 @@ def main():
     if sync is not None:
       # every bucket is averaged over ranks before ITS optimizers run: the decoder-side bucket (reduced under the
       # encoder backward GEMM) first, so that its Adam, SGD and prox run under the encoder bucket's all-reduce
+      # (timed steps: events on the compute stream around each wait = the time that stream stood still for a bucket,
+      # i.e. the communication the step did NOT hide)
+      marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
+      if timed: marks[0].record()
       sync.wait_decoder()
+      if timed: marks[1].record()
       eng.adam_step(LR, part="dec")
       eng.sgd_prox_step(WS_LR, t_prox)
+      if timed: marks[2].record()
       sync.wait_encoder()
+      if timed:
+        marks[3].record()
+        comm_marks.append(marks)
       eng.adam_step(LR, part="enc")
     else:
       eng.adam_step(LR)
@@ -325,6 +335,15 @@ def main():
                     "three bf16 terms, six products); extra.ms_per_step_fp32_matrix_instructions: OIVAE_ENC=fp32 "
                     "OIVAE_DEC=v4",
     }
+    if sync is not None and comm_marks:
+      n = len(comm_marks)
+      out["comm"] = {"backend": torch.distributed.get_backend(),
+                     "bucket_bytes": {"decoder_side": int(sync.dec.numel()) * 4, "encoder": int(sync.enc.numel()) * 4},
+                     "exposed_wait_ms": {"decoder_side": sum(m[0].elapsed_time(m[1]) for m in comm_marks) / n,
+                                         "encoder": sum(m[2].elapsed_time(m[3]) for m in comm_marks) / n},
+                     "note": "rank 0's compute stream, HIP events around the waits for the two gradient buckets: the "
+                             "decoder-side bucket is reduced under the encoder backward GEMM, the encoder bucket under "
+                             "the decoder side's Adam, SGD and proximal step"}
     if rehearse:
       out["rehearsal"] = "all %d ranks on one GPU over gloo: code-path check only, the numbers are meaningless" % world
     if world == 1:

@@ -191,17 +191,39 @@ __global__ __launch_bounds__(256) void theta_prior_kernel(ThetaSegs sg, float in
   if (threadIdx.x == 0) part[(int64_t)q * gridDim.x + blockIdx.x] = sm[0];
 }
 
-__global__ __launch_bounds__(256) void penalty_kernel(const float* __restrict__ Ws, int64_t rows, int H,
+// sum over rows of ||Ws[row, :]||_2.  L lanes per row (a power of two, 16 bytes per lane and pass) when rows are
+// 16-byte aligned -- a wave then reads whole rows back to back instead of 64 rows 4 H bytes apart -- else one thread
+// per row.
+__global__ __launch_bounds__(256) void penalty_kernel(const float* __restrict__ Ws, int64_t rows, int H, int L,
                                                       double* __restrict__ part) {
   __shared__ double sm[256];
   double acc = 0.0;
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; r < rows; r += stride) {
-    const float* w = Ws + r * H;
-    float s = 0.f;
-    for (int h = 0; h < H; ++h) s += w[h] * w[h];
-    acc += (double)sqrtf(s);
+  if (L > 0) {
+    const int sub = threadIdx.x & (L - 1);
+    int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / L;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x / L;
+    const int64_t rounds = (rows + stride - 1) / stride;   // every lane of a row group runs the same number of passes
+    for (int64_t it = 0; it < rounds; ++it, r += stride) {
+      float s = 0.f;
+      if (r < rows) {
+        const float4* w = reinterpret_cast<const float4*>(Ws + r * H);
+        for (int h = sub; h < (H >> 2); h += L) {
+          const float4 q = w[h];
+          s += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+        }
+      }
+      for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (sub == 0 && r < rows) acc += (double)sqrtf(s);
+    }
+  } else {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; r < rows; r += stride) {
+      const float* w = Ws + r * H;
+      float s = 0.f;
+      for (int h = 0; h < H; ++h) s += w[h] * w[h];
+      acc += (double)sqrtf(s);
+    }
   }
   sm[threadIdx.x] = acc;
   __syncthreads();
@@ -370,7 +392,12 @@ extern "C" int oivae_finalize_f32(const oivae_shape_t* shape, const oivae_tensor
   hipLaunchKernelGGL(theta_prior_kernel, dim3((unsigned)(w.n_theta / 4), 4), dim3(256), 0, st, sg, inv_var, w.theta_part);
   OIVAE_LAUNCH_CHECK();
   const int64_t rows = (int64_t)s.G * s.K;
-  hipLaunchKernelGGL(penalty_kernel, dim3((unsigned)w.n_pen), dim3(256), 0, st, params->Ws, rows, s.H, w.pen_part);
+  int pen_lanes = 0;   // lanes per row: the largest power of two <= min(64, H / 4)
+  if (s.H % 4 == 0 && (reinterpret_cast<uintptr_t>(params->Ws) & 15) == 0) {
+    pen_lanes = 1;
+    while (pen_lanes * 2 <= s.H / 4 && pen_lanes < 64) pen_lanes *= 2;
+  }
+  hipLaunchKernelGGL(penalty_kernel, dim3((unsigned)w.n_pen), dim3(256), 0, st, params->Ws, rows, s.H, pen_lanes, w.pen_part);
   OIVAE_LAUNCH_CHECK();
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, w.kl_part, w.n_kl, w.ll_part, w.n_ll,
                      w.theta_part, w.n_theta, w.pen_part, w.n_pen, n_theta_elems, sigma_theta, lam,

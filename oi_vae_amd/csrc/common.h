@@ -61,7 +61,7 @@ struct Workspace {
 
 constexpr int kMaxPartials = 16384;
 constexpr int kEncEpiBlocks = 2048;  // cap on enc_fwd_epilogue blocks (= KL partials)
-constexpr int kBiasBlocks = 256;     // cap on enc_bwd_pre blocks (= bias-gradient partials)
+constexpr int kBiasBlocks = 1024;    // cap on enc_bwd_pre blocks (= bias-gradient partials)
 constexpr int kMaxEncSplits = 8;     // split-K partial images of the encoder pre-activations  // cap on per-kernel block counts that emit partials
 
 // sizes of the decoder parameter block, in floats, in slab order:

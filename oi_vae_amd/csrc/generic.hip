@@ -594,16 +594,7 @@ __global__ __launch_bounds__(256) void enc_bwd_pre(int64_t B, int K, int S, cons
   const float invB = 1.0f / (float)B;
   const bool fixed_col = (256 % K) == 0;  // then thread t always meets column t % K: sums stay in registers
   double smu = 0.0, sda = 0.0;
-  for (int64_t i = r0 * K + tid; i < r1 * K; i += 256) {
-    const int64_t b = i / K;
-    const int k = (int)(i - b * K);
-    float sdz = 0.f, sdze = 0.f;
-    for (int s = 0; s < S; ++s) {
-      const int64_t n = (int64_t)s * B + b;
-      const float d = dz[n * dz_sn + k * dz_sk];
-      sdz += d;
-      sdze = fmaf(d, eps[n * K + k], sdze);
-    }
+  auto element = [&](int64_t i, int64_t b, int k, float sdz, float sdze) {
     const float mp = prior_mu[b * prior_stride + k], sp = prior_sigma[b * prior_stride + k];
     const float sq = sig_q[i];
     const float dmu = sdz + ((mu_q[i] - mp) / (sp * sp)) * invB;
@@ -613,6 +604,40 @@ __global__ __launch_bounds__(256) void enc_bwd_pre(int64_t B, int K, int S, cons
     dpre[b * 2 * K + K + k] = da;
     if (fixed_col) { smu += (double)dmu; sda += (double)da; }
     else { atomicAdd(&col[k], (double)dmu); atomicAdd(&col[K + k], (double)da); }  // LDS; odd K only (order-dependent in the last bits)
+  };
+  if (dz_sn == 1 && S == 1) {
+    // dz arrives transposed ([K, N], the matrix-core decoders): consecutive threads of the element loop below meet
+    // consecutive k, i.e. addresses N floats apart.  Tiles of 64 rows are therefore read along n (256-byte runs) into
+    // LDS first (round 2: 84 -> 25 us at 65536 rows).
+    float* sT = reinterpret_cast<float*>(col + 2 * K + 512);   // [K][65]
+    for (int64_t t0 = r0; t0 < r1; t0 += 64) {
+      const int nr = (int)((r1 - t0 < 64) ? r1 - t0 : 64);
+      __syncthreads();   // the tile before this one has been consumed
+      for (int k = tid >> 6; k < K; k += 4) {
+        const int r = tid & 63;
+        sT[k * 65 + r] = (r < nr) ? dz[(t0 + r) + k * dz_sk] : 0.f;
+      }
+      __syncthreads();
+      for (int64_t i = t0 * K + tid; i < (t0 + nr) * K; i += 256) {
+        const int64_t b = i / K;
+        const int k = (int)(i - b * K);
+        const float d = sT[k * 65 + (int)(b - t0)];
+        element(i, b, k, d, d * eps[i]);
+      }
+    }
+  } else {
+    for (int64_t i = r0 * K + tid; i < r1 * K; i += 256) {
+      const int64_t b = i / K;
+      const int k = (int)(i - b * K);
+      float sdz = 0.f, sdze = 0.f;
+      for (int s = 0; s < S; ++s) {
+        const int64_t n = (int64_t)s * B + b;
+        const float d = dz[n * dz_sn + k * dz_sk];
+        sdz += d;
+        sdze = fmaf(d, eps[n * K + k], sdze);
+      }
+      element(i, b, k, sdz, sdze);
+    }
   }
   if (fixed_col) {
     // threads t, t+K, t+2K, ... hold the same column: fold them in a fixed order
@@ -633,9 +658,14 @@ __global__ __launch_bounds__(256) void enc_bwd_pre(int64_t B, int K, int S, cons
 
 // one block per column j: the per-block partials are folded by a fixed-shape tree (deterministic)
 __global__ __launch_bounds__(256) void enc_bwd_bias_final(const double* __restrict__ bias_part, int nblk, int K,
-                                                          float* __restrict__ dbmu, float* __restrict__ dbsig) {
+                                                          float* __restrict__ dbmu, float* __restrict__ dbsig,
+                                                          uint32_t* __restrict__ rng) {
   __shared__ double sm[256];
   const int j = blockIdx.x;
+  // the ranges the fp16 backward GEMM's helpers accumulate into with atomicMax start at zero (x3_encoder.hip:
+  // [2] max|dpre|, [8] max|x| the kernel reads, [9] its redo flag); done here, one kernel ahead of them, instead of
+  // two memsets of their own
+  if (rng != nullptr && j == 0 && threadIdx.x == 0) { rng[2] = 0u; rng[8] = 0u; rng[9] = 0u; }
   double acc = 0.0;
   for (int b = threadIdx.x; b < nblk; b += 256) acc += bias_part[(int64_t)b * 2 * K + j];
   sm[threadIdx.x] = acc;
@@ -913,12 +943,12 @@ int oivae::encoder_bwd_run(const oivae_shape_t& s, const oivae_tensors_t* grads,
                            double* bias_part, int n_bias, uint32_t* x3_img, uint32_t* rng, float* bwd_part, hipStream_t st) {
   const bool dz_transposed = plan_decoder(s, B * (int64_t)S).mfma;
   const int64_t dz_sn = dz_transposed ? 1 : s.K, dz_sk = dz_transposed ? B * (int64_t)S : 1;
-  const size_t pre_lds = sizeof(double) * (2 * (size_t)s.K + 512);
+  const size_t pre_lds = sizeof(double) * (2 * (size_t)s.K + 512) + ((dz_sn == 1 && S == 1) ? sizeof(float) * 65 * (size_t)s.K : 0);
   hipLaunchKernelGGL(enc_bwd_pre, dim3((unsigned)n_bias), dim3(256), pre_lds, st, B, s.K, S, dz, dz_sn, dz_sk, eps, c,
                      prior_mu, prior_sigma, prior_rows == 1 ? 0 : s.K, mu_q, sig_q, ea, dpre, bias_part);
   OIVAE_LAUNCH_CHECK();
   hipLaunchKernelGGL(enc_bwd_bias_final, dim3((unsigned)(2 * s.K)), dim3(256), 0, st, bias_part, n_bias,
-                     s.K, grads->enc_bmu, grads->enc_bsig);
+                     s.K, grads->enc_bmu, grads->enc_bsig, rng);
   OIVAE_LAUNCH_CHECK();
   if (x3_encoder_bwd_applies(s, B)) {
     if (int rc = launch_encoder_bwd_x3(s, grads, X, dpre, B, x3_img, rng, st)) return rc;

@@ -295,7 +295,10 @@ constexpr int kH2Row = 20;
 constexpr int kH2Sub = 128 * kH2Row + 16;   // sub-step images 16 banks apart (stores bank over 32 dwords): the producers' stores stay conflict-free
 constexpr int kH2Buf = 4 * kH2Sub;
 
-__global__ __launch_bounds__(256) void absmax_f32(const float* __restrict__ v, int64_t n, uint32_t* __restrict__ out) {
+// max|v| over one array, or over two of the same length (blockIdx.y), into one word
+__global__ __launch_bounds__(256) void absmax_f32(const float* __restrict__ v0, const float* __restrict__ v1, int64_t n,
+                                                  uint32_t* __restrict__ out) {
+  const float* __restrict__ v = blockIdx.y ? v1 : v0;
   float m = 0.f;
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
   if ((reinterpret_cast<uintptr_t>(v) & 15) == 0) {   // 16 bytes per lane, scalar tail
@@ -825,6 +828,8 @@ int x3_encoder_fwd_splits(const oivae_shape_t& s, int64_t B) {
 // of two and a gated second launch repeats the kernel when they differ.  No host-side memory of earlier calls: every
 // entry point is a function of its arguments and computes with the scale of its own X's maximum.
 // test hook: OIVAE_ENC=bf16 keeps the three-term bf16 kernels
+// 16 floats per thread and up: enough workgroups to fill the chip, one atomic each
+static inline unsigned absmax_blocks(int64_t n) { const int64_t b = (n + 4095) / 4096; return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
 static inline bool h2_enabled() { return test_hooks().enc != 'b'; }
 void launch_range_guard(uint32_t* rng, int seen, int flag, hipStream_t st);  // mfma_decoder.hip
 
@@ -841,8 +846,8 @@ int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params,
   const dim3 grid((unsigned)((B + 127) / 128), (unsigned)(Jp / 128), (unsigned)splits);
   OIVAE_HIP_CHECK(hipMemsetAsync(rng, 0, 16, st));   // [0] max|X| of this call, [1] max|W|, [2] max|dpre|, [3] redo flag
   if (h2_enabled()) {
-    hipLaunchKernelGGL(absmax_f32, dim3(256), dim3(256), 0, st, params->enc_Wmu, (int64_t)s.K * s.D, rng + 1);
-    hipLaunchKernelGGL(absmax_f32, dim3(256), dim3(256), 0, st, params->enc_Wsig, (int64_t)s.K * s.D, rng + 1);
+    hipLaunchKernelGGL(absmax_f32, dim3(absmax_blocks((int64_t)s.K * s.D), 2), dim3(256), 0, st, params->enc_Wmu,
+                       params->enc_Wsig, (int64_t)s.K * s.D, rng + 1);
     OIVAE_LAUNCH_CHECK();
     hipLaunchKernelGGL(h2_split_rows, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, params->enc_Wmu,
                        params->enc_Wsig, s.K, J, s.D, Jp, KT, wimg, rng);
@@ -877,9 +882,9 @@ int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, 
   const int BT = (int)((B + 31) / 32);
   const int64_t chunks = (int64_t)Jp * BT * 4;
   if (h2_enabled()) {
-    OIVAE_HIP_CHECK(hipMemsetAsync(rng + 2, 0, 4, st));
-    OIVAE_HIP_CHECK(hipMemsetAsync(rng + 8, 0, 8, st));
-    hipLaunchKernelGGL(absmax_f32, dim3(256), dim3(256), 0, st, dpre, B * (int64_t)J, rng + 2);
+    // rng[2], rng[8], rng[9] were zeroed by enc_bwd_bias_final, the kernel before this one (generic.hip: encoder_bwd_run)
+    hipLaunchKernelGGL(absmax_f32, dim3(absmax_blocks(B * (int64_t)J), 1), dim3(256), 0, st, dpre, (const float*)nullptr,
+                       B * (int64_t)J, rng + 2);
     OIVAE_LAUNCH_CHECK();
     hipLaunchKernelGGL(h2_split_cols, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, dpre, B, J, Jp, BT, img, rng);
     OIVAE_LAUNCH_CHECK();
