@@ -103,12 +103,12 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
   w->kl_part = reinterpret_cast<double*>(take(sizeof(double) * kEncEpiBlocks));
   w->n_ll = plan.flat ? flat_decoder_blocks(s) : s.G * plan.chunks;
   w->ll_part = reinterpret_cast<double*>(take(sizeof(double) * kMaxPartials));
-  w->n_bias = enc_bias_blocks(B);  // at least 64 rows per block
+  w->n_bias = enc_bias_blocks(B);  // at least 16 rows per block
   w->bias_part = reinterpret_cast<double*>(take(sizeof(double) * kBiasBlocks * 2 * s.K));
   w->n_theta = 2048;  // 512 blocks per generator parameter array; every slot written each step
   w->theta_part = reinterpret_cast<double*>(take(sizeof(double) * 2048));
   {
-    int64_t pb = ((int64_t)s.G * s.K + 255) / 256;
+    int64_t pb = ((int64_t)s.G * s.K + 63) / 64;   // few passes per thread: the kernel is a chain of dependent loads
     w->n_pen = (int32_t)(pb > 1024 ? 1024 : pb);  // = penalty_kernel's grid: every slot written
   }
   w->pen_part = reinterpret_cast<double*>(take(sizeof(double) * 1024));

@@ -138,7 +138,7 @@ int encoder_bwd_run(const oivae_shape_t& s, const oivae_tensors_t* grads, const 
                     const float* eps, float c, const float* prior_mu, const float* prior_sigma, int32_t prior_rows,
                     const float* mu_q, const float* sig_q, const float* ea, const float* dz, float* dpre,
                     double* bias_part, int n_bias, uint32_t* x3_img, uint32_t* rng, float* bwd_part, hipStream_t st);
-inline int enc_bias_blocks(int64_t B) { const int64_t bb = (B + 63) / 64; return (int)(bb > kBiasBlocks ? kBiasBlocks : bb); }
+inline int enc_bias_blocks(int64_t B) { const int64_t bb = (B + 15) / 16; return (int)(bb > kBiasBlocks ? kBiasBlocks : bb); }
 // noalloc.hip: resolves the device address of the static scratch array for `device` (which must be current)
 int noalloc_scratch_setup(int device);
 // decoder gradient partials [chunks][DecLayout::total] -> the six gradient tensors, summed in chunk order (one launch)

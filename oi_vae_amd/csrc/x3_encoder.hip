@@ -304,8 +304,17 @@ __global__ __launch_bounds__(256) void absmax_f32(const float* __restrict__ v0, 
   if ((reinterpret_cast<uintptr_t>(v) & 15) == 0) {   // 16 bytes per lane, scalar tail
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int64_t n4 = n >> 2;
-    for (int64_t i = tid; i < n4; i += nth) {
-      const f4 q = reinterpret_cast<const f4*>(v)[i];
+    const f4* __restrict__ v4 = reinterpret_cast<const f4*>(v);
+    int64_t i = tid;
+    for (; i + 7 * nth < n4; i += 8 * nth) {   // eight loads in flight per lane: few workgroups must cover the latency
+      f4 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = v4[i + u * nth];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m = fmaxf(fmaxf(m, fmaxf(fabsf(q[u][0]), fabsf(q[u][1]))), fmaxf(fabsf(q[u][2]), fabsf(q[u][3])));
+    }
+    for (; i < n4; i += nth) {
+      const f4 q = v4[i];
       m = fmaxf(fmaxf(m, fmaxf(fabsf(q[0]), fabsf(q[1]))), fmaxf(fabsf(q[2]), fabsf(q[3])));
     }
     for (int64_t i = 4 * n4 + tid; i < n; i += nth) m = fmaxf(m, fabsf(v[i]));
@@ -314,10 +323,15 @@ __global__ __launch_bounds__(256) void absmax_f32(const float* __restrict__ v0, 
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  __shared__ float part[4];   // one atomic per workgroup: thousands of atomics on one address take 14 ns each
+  __shared__ float part[4];   // at most one atomic per workgroup: thousands of atomics on one address take 14 ns each
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
+  if (threadIdx.x == 0) {
+    // ... and none when the word already holds as much (a plain coherent load: of n workgroups with like maxima only
+    // about ln n raise the word)
+    const uint32_t mine = __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
+    if (__hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < mine) atomicMax(out, mine);
+  }
 }
 
 // image of dpre^T in two fp16 terms: img[j][bt][s][piece][h][4 dwords], scaled by the power of two of rng[2]
@@ -604,32 +618,52 @@ __global__ __launch_bounds__(768, 1) void enc_h2_bwd_gemm(const float* __restric
 __global__ __launch_bounds__(256) void h2_split_rows(const float* __restrict__ W0, const float* __restrict__ W1,
                                                      int rows0, int rows, int Kd, int rows_pad, int KT,
                                                      uint32_t* __restrict__ img, const uint32_t* __restrict__ rng) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)rows_pad * KT * 4;
-  if (i >= total) return;
+  const int64_t half = (total + 1) >> 1;
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i0 >= half) return;
   float sc, inv;
   h2_scale_of(rng[1], &sc, &inv);
-  const int row = (int)(i / (KT * 4)), c = (int)(i % (KT * 4));
-  const int kt = c >> 2, s = (c >> 1) & 1, h = c & 1;
-  const int k = 8 * c;
-  float v[8];
+  // two items per thread (i0 and i0 + half), both loads requested before either is split: 32 bytes per thread in
+  // flight left the kernel at 2.5 TB/s
+  float v[2][8];
+  int64_t dsto[2];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = 0.f;
-  if (row < rows) {
-    const float* src = (row < rows0 ? W0 + (int64_t)row * Kd : W1 + (int64_t)(row - rows0) * Kd);
+  for (int u = 0; u < 2; ++u) {
+    const int64_t i = i0 + u * half;
+    const bool on = i < total;
+    const int row = on ? (int)(i / (KT * 4)) : 0, c = on ? (int)(i % (KT * 4)) : 0;
+    const int kt = c >> 2, s = (c >> 1) & 1, h = c & 1;
+    const int k = 8 * c;
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (k + e < Kd) v[e] = src[k + e] * sc;
+    for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
+    if (on && row < rows) {
+      const float* src = (row < rows0 ? W0 + (int64_t)row * Kd : W1 + (int64_t)(row - rows0) * Kd);
+      if (k + 8 <= Kd && ((reinterpret_cast<uintptr_t>(src + k) & 15) == 0)) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + k), b = *reinterpret_cast<const f32x4*>(src + k + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[u][e] = a[e]; v[u][4 + e] = b[e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (k + e < Kd) v[u][e] = src[k + e];
+      }
+    }
+    dsto[u] = on ? (((int64_t)row * KT + kt) * 2 + s) * 16 + 4 * h : -1;
   }
-  u32x4 Q[2];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const Split2 q = split2_pair(v[2 * e], v[2 * e + 1]);
-    Q[0][e] = q.h; Q[1][e] = q.l;
+  for (int u = 0; u < 2; ++u) {
+    if (dsto[u] < 0) continue;
+    u32x4 Q[2];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const Split2 q = split2_pair(v[u][2 * e] * sc, v[u][2 * e + 1] * sc);
+      Q[0][e] = q.h; Q[1][e] = q.l;
+    }
+    uint32_t* dst = img + dsto[u];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(dst + 8 * p) = Q[p];
   }
-  uint32_t* dst = img + (((int64_t)row * KT + kt) * 2 + s) * 16 + 4 * h;
-#pragma unroll
-  for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(dst + 8 * p) = Q[p];
 }
 
 __global__ void h2_fwd_guard(uint32_t* rng) {
@@ -828,8 +862,9 @@ int x3_encoder_fwd_splits(const oivae_shape_t& s, int64_t B) {
 // of two and a gated second launch repeats the kernel when they differ.  No host-side memory of earlier calls: every
 // entry point is a function of its arguments and computes with the scale of its own X's maximum.
 // test hook: OIVAE_ENC=bf16 keeps the three-term bf16 kernels
-// 16 floats per thread and up: enough workgroups to fill the chip, one atomic each
-static inline unsigned absmax_blocks(int64_t n) { const int64_t b = (n + 4095) / 4096; return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
+// few workgroups (they all finish together and each ends in an atomic on one word: 2048 of them took 27 us where 256
+// take 10), many loads in flight per lane instead
+static inline unsigned absmax_blocks(int64_t n, int arrays) { const int64_t b = (n + 8191) / 8192, cap = 256 / arrays; return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b)); }
 static inline bool h2_enabled() { return test_hooks().enc != 'b'; }
 void launch_range_guard(uint32_t* rng, int seen, int flag, hipStream_t st);  // mfma_decoder.hip
 
@@ -846,10 +881,10 @@ int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params,
   const dim3 grid((unsigned)((B + 127) / 128), (unsigned)(Jp / 128), (unsigned)splits);
   OIVAE_HIP_CHECK(hipMemsetAsync(rng, 0, 16, st));   // [0] max|X| of this call, [1] max|W|, [2] max|dpre|, [3] redo flag
   if (h2_enabled()) {
-    hipLaunchKernelGGL(absmax_f32, dim3(absmax_blocks((int64_t)s.K * s.D), 2), dim3(256), 0, st, params->enc_Wmu,
+    hipLaunchKernelGGL(absmax_f32, dim3(absmax_blocks((int64_t)s.K * s.D, 2), 2), dim3(256), 0, st, params->enc_Wmu,
                        params->enc_Wsig, (int64_t)s.K * s.D, rng + 1);
     OIVAE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(h2_split_rows, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, params->enc_Wmu,
+    hipLaunchKernelGGL(h2_split_rows, dim3((unsigned)(((chunks + 1) / 2 + 255) / 256)), dim3(256), 0, st, params->enc_Wmu,
                        params->enc_Wsig, s.K, J, s.D, Jp, KT, wimg, rng);
     OIVAE_LAUNCH_CHECK();
     const size_t lds2 = sizeof(uint32_t) * 2 * kH2Buf;
@@ -883,7 +918,7 @@ int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, 
   const int64_t chunks = (int64_t)Jp * BT * 4;
   if (h2_enabled()) {
     // rng[2], rng[8], rng[9] were zeroed by enc_bwd_bias_final, the kernel before this one (generic.hip: encoder_bwd_run)
-    hipLaunchKernelGGL(absmax_f32, dim3(absmax_blocks(B * (int64_t)J), 1), dim3(256), 0, st, dpre, (const float*)nullptr,
+    hipLaunchKernelGGL(absmax_f32, dim3(absmax_blocks(B * (int64_t)J, 1), 1), dim3(256), 0, st, dpre, (const float*)nullptr,
                        B * (int64_t)J, rng + 2);
     OIVAE_LAUNCH_CHECK();
     hipLaunchKernelGGL(h2_split_cols, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, dpre, B, J, Jp, BT, img, rng);
