@@ -148,6 +148,49 @@ def test_wide_prox_full_size_bit_exact_and_idempotent_zero_set():
   assert np.all(left[newly] <= 1.1e-6) and np.all(left[(m2 == 0)] > 0.9e-6)
 
 
+@pytest.mark.parametrize("H,sgd", [(8, True), (16, False), (16, True), (32, False), (32, True)])
+def test_persistent_prox_kernel_bit_exact_with_and_without_sgd(H, sgd):
+  """Launches of 524288 rows and more with H in {8, 16, 32} take the persistent kernel that keeps the rsqrt14 table
+  in LDS (prox.hip, path C): a ragged row count (the last pass is partial, and so is the last pair's workgroup)
+  against the C oracle, bit for bit, with norms and mask; the same rows in one small launch each side of the
+  threshold (path B) must give the same bits."""
+  import ctypes
+  from oi_vae_amd import _lib
+  from oracle import prox_oracle
+  L = _lib.init_device(0)
+  rows = 4 * 256 * 512 + 4099
+  g = torch.Generator(device="cuda").manual_seed(40 + H)
+  W = torch.randn(rows, H, generator=g, device="cuda") * torch.rand(rows, 1, generator=g, device="cuda")
+  dW = torch.randn(rows, H, generator=g, device="cuda")
+  W[5].zero_(); W[rows - 1] *= 1e-20
+  lr = 0.25
+  t = float(torch.sqrt((W.double() ** 2).sum(-1)).median())
+  # torch.optim.SGD on CPU rounds w + (-lr) g once (fma): in float64 the sum is exact before that one rounding
+  start = (W.double() - lr * dW.double()).float() if sgd else W
+  want, wmask, wnorm = prox_oracle.proximal_step(start.cpu().numpy().reshape(1, rows, H), t)
+  st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+  def run(Wt, n):
+    mask = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    norms = torch.zeros(n, dtype=torch.float32, device="cuda")
+    if sgd:
+      _lib.check(L.oivae_sgd_prox_f32(Wt.data_ptr(), dW.data_ptr(), n, H, lr, t, 1, mask.data_ptr(), norms.data_ptr(), st), "sgd_prox")
+    else:
+      _lib.check(L.oivae_prox_f32(Wt.data_ptr(), n, H, t, mask.data_ptr(), norms.data_ptr(), st), "prox")
+    torch.cuda.synchronize()
+    return Wt.cpu().numpy(), mask.cpu().numpy(), norms.cpu().numpy()
+
+  got, gmask, gnorm = run(W.clone(), rows)
+  assert np.array_equal(got.view(np.uint32), want.reshape(rows, H).view(np.uint32))
+  assert np.array_equal(gmask, wmask.reshape(rows))
+  assert np.array_equal(gnorm.view(np.uint32), wnorm.reshape(rows).astype(np.float32).view(np.uint32))
+  assert 0.4 < gmask.mean() < 0.6
+  small = 100000   # below the threshold: the two-round-trip kernel
+  got_s, gmask_s, gnorm_s = run(W[:small].clone(), small)
+  assert np.array_equal(got_s.view(np.uint32), got[:small].view(np.uint32))
+  assert np.array_equal(gmask_s, gmask[:small]) and np.array_equal(gnorm_s.view(np.uint32), gnorm[:small].view(np.uint32))
+
+
 _ENC = r'''
 import os, sys
 sys.path.insert(0, %(root)r)

@@ -9,6 +9,8 @@ import torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from oi_vae_amd import _lib  # noqa: E402
 
+if len(sys.argv) > 1:   # another build of the library (a scratch build with other -DOIVAE_PROX_R8 / _R64)
+  _lib.LIB_PATH = sys.argv[1]
 L = _lib.init_device(0)
 Gp, Kp, Hp = 8192, 256, 8
 gen = torch.Generator(device="cuda").manual_seed(3)
