@@ -98,6 +98,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
     float* tWs = scr + 64 * LW;
     float* tW2 = scr + 2 * 64 * LW;
     __syncthreads();
+    OIVAE_PROBE_SETUP(0);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int e = 4 * (tid + 512 * j);
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
       sC3[tid] = (a.inv / sig) / sig;
     }
     __syncthreads();
+    OIVAE_PROBE_SETUP(1);
     f32x16 acc = (f32x16)(0.f);   // A[m][k] = sum_h W1[m][h] Ws[k][h] on the fp32 matrix instruction
     const int mt = sw >> 1, kt = sw & 1;
     if (chainw) {
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
       for (int r = 0; r < 16; ++r) tW1[(32 * mt + OIVAE_ROW(r, hh)) * LW + 32 * kt + l31] = acc[r];
     }
     __syncthreads();
+    OIVAE_PROBE_SETUP(2);
     const float* A = tW1;
     uint32_t* red = const_cast<uint32_t*>(flags) + 16 + 5 * q;
     float* gbound = scr + 3 * 64 * LW;   // [64]
@@ -140,8 +143,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
         mA = fmaxf(mA, fabsf(A[o]));
         mW = fmaxf(mW, fabsf(tW2[o]));
       }
-      atomicMax(red + 0, __float_as_uint(mA));
-      atomicMax(red + 1, __float_as_uint(mW));
+      float gmx = 0.f;
       {   // eight lanes per output dimension d: sum_m |W2[d][m]|
         const int d = tid >> 3, part = tid & 7;
         float rs = 0.f;
@@ -153,11 +155,24 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
         if (part == 0) {
           const float gb = sC3[d] * (rs + fabsf(sb2[d]) + __uint_as_float(a.rng[0]));
           gbound[d] = gb;
-          atomicMax(red + 2, __float_as_uint(gb));
+          gmx = gb;
         }
+      }
+      // one LDS atomic per wave and maximum: 512 lanes on one LDS word took 6 of the set-up's 14 us per group
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        mA = fmaxf(mA, __shfl_xor(mA, o));
+        mW = fmaxf(mW, __shfl_xor(mW, o));
+        gmx = fmaxf(gmx, __shfl_xor(gmx, o));
+      }
+      if (lane == 0) {
+        atomicMax(red + 0, __float_as_uint(mA));
+        atomicMax(red + 1, __float_as_uint(mW));
+        atomicMax(red + 2, __float_as_uint(gmx));
       }
     }
     __syncthreads();
+    OIVAE_PROBE_SETUP(3);
     {   // eight lanes per hidden unit m: sum_d |W2[d][m]| gbound[d]
       const int m = tid & 63, part = tid >> 6;
       float cs = 0.f;
@@ -172,9 +187,12 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
       float cs = 0.f;
 #pragma unroll
       for (int p8 = 0; p8 < 8; ++p8) cs += csp[p8 * 64 + tid];
-      atomicMax(red + 3, __float_as_uint(cs));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cs = fmaxf(cs, __shfl_xor(cs, o));
+      if (lane == 0) atomicMax(red + 3, __float_as_uint(cs));
     }
     __syncthreads();
+    OIVAE_PROBE_SETUP(4);
     float q1, q2, qz, qg, qd, i1, i2, iz, ig, id;
     {
       const float mA = __uint_as_float(red[0]), mW = __uint_as_float(red[1]);
@@ -190,6 +208,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
     invW[q] = uni(ig * (1.0f / kSt)); invP[q] = uni(id * iz);
     invG[q] = uni(ig); invD[q] = uni(id); omtC[q] = uni((i2 * ig) * qd);
     __syncthreads();   // every thread has read the maxima before the biases change
+    OIVAE_PROBE_SETUP(5);
     if (tid < 64) {
       sb1[tid] *= q1 * qz;    // accumulator initial values in the products' scaled units
       sb2[tid] *= q2 * kSt;
@@ -213,6 +232,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
           *reinterpret_cast<x3_u32x4*>(img + (q * 3 + w) * 4096 + ((((r >> 4) * 2 + kk) * 2 + p) * 64 + iq * 16 + (r & 15)) * 4) = f.p[p];
       }
     }
+    OIVAE_PROBE_SETUP(6);
     OIVAE_PROBE(1 + q);
   }
   __syncthreads();
@@ -615,12 +635,16 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
       }
       __syncthreads();
     };
+    OIVAE_PROBE_END(0);
     stage_acc(dW2a);
+    OIVAE_PROBE_END(1);
     if (worker) {
       float* dst = a.gW2 + cs + (int64_t)gq * DG * M;
       for (int idx = wtid; idx < 4096; idx += 256) dst[idx] = stage[idx] + stage[4096 + idx];
     }
+    OIVAE_PROBE_END(2);
     stage_acc(Pa);
+    OIVAE_PROBE_END(3);
     if (worker) {
       for (int idx = wtid; idx < 4096; idx += 256) {
         const int o = (idx >> 6) * LW + (idx & 63);
@@ -635,6 +659,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
       ssum[wp * 192 + 128 + lane] = cs_da1;
     }
     __syncthreads();
+    OIVAE_PROBE_END(4);
     if (worker) {
       const int it = sw >> 1, ht = sw & 1;
       f32x16 acc = (f32x16)(0.f);  // dW1[m][h] = sum_k P[m][k] Ws[k][h]
@@ -654,6 +679,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) d2[(32 * it + OIVAE_ROW(r, hh)) * H + 32 * ht + l31] = acc[r];
     }
+    OIVAE_PROBE_END(5);
     float* sred = stage;   // the partials were consumed before the last barrier
     if (worker && wtid < 64) {
       const float s_gmu = ssum[wtid] + ssum[192 + wtid];
@@ -677,6 +703,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
       for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
       if (wtid == 0) a.ll_part[(int64_t)chunk * a.G + gq] = tot;
     }
+    OIVAE_PROBE_END(6);
   }
   OIVAE_PROBE(6);
 }

@@ -1712,8 +1712,22 @@ __device__ __forceinline__ x3_u32x2 lds_read_tr16(const char* p) {
 __device__ unsigned long long g_probe[8192 * 8];
 #define OIVAE_PROBE(i) \
   do { if (threadIdx.x == 0) g_probe[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 8 + (i)] = wall_clock64(); } while (0)
+#define OIVAE_PROBE_SETUP(i) do {} while (0)
+#elif defined(OIVAE_ABL_TIMES2)   // the sub-phases of the set-up of a pair's SECOND group (dec_x3_64s; tools/dec_probe.py --setup)
+__device__ unsigned long long g_probe[8192 * 8];
+#define OIVAE_PROBE(i) do {} while (0)
+#define OIVAE_PROBE_SETUP(i) \
+  do { if (threadIdx.x == 0 && q == 1) g_probe[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define OIVAE_PROBE(i) do {} while (0)
+#define OIVAE_PROBE_SETUP(i) do {} while (0)
+#endif
+#ifdef OIVAE_ABL_TIMES3   // the sub-phases of the end of the kernel for a pair's second group (tools/dec_probe.py --end)
+__device__ unsigned long long g_probe[8192 * 8];
+#define OIVAE_PROBE_END(i) \
+  do { if (threadIdx.x == 256 && q == 1) g_probe[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define OIVAE_PROBE_END(i) do {} while (0)
 #endif
 
 // timing-only stand-in (tools/dec_ablate.py C16 / W16): the flops of one 32x32x16 product issued as two 16x16x32
@@ -2603,7 +2617,7 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
 
 }  // namespace oivae
 
-#ifdef OIVAE_ABL_TIMES
+#if defined(OIVAE_ABL_TIMES) || defined(OIVAE_ABL_TIMES2) || defined(OIVAE_ABL_TIMES3)
 extern "C" int oivae_probe_read(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(oivae::g_probe), sizeof(unsigned long long) * (size_t)n);
 }

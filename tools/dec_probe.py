@@ -18,7 +18,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oi_vae_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "tools", "probe", "liboivae_abl_TIMES.so")
+SETUP = "--setup" in sys.argv   # tools/build_ablation.sh TIMES2: the sub-phases of the set-up of a pair's second group
+if SETUP:
+  sys.argv.remove("--setup")
+END = "--end" in sys.argv       # tools/build_ablation.sh TIMES3: the sub-phases of the end of the kernel, second group
+if END:
+  sys.argv.remove("--end")
+_lib.LIB_PATH = os.path.join(ROOT, "tools", "probe", "liboivae_abl_TIMES3.so" if END else ("liboivae_abl_TIMES2.so" if SETUP else "liboivae_abl_TIMES.so"))
 import bench  # noqa: E402
 
 
@@ -41,6 +47,15 @@ def main():
     t = buf.reshape(nwg, 8).astype(np.int64)
     t0 = t[:, 0].min()
     us = (t - t0) / 100.0     # 100 MHz
+    if SETUP or END:
+      names = (["matrices and vectors into LDS", "A = W1 Ws^T", "maxima and gmu bounds", "da1 bounds", "scales", "images"] if SETUP else
+               ["dW2 partials into LDS", "dW2 summed and stored", "P partials into LDS", "P summed, W1 and Ws into LDS", "dW1 and dWs products", "bias and sigma gradients"])
+      d = np.diff(us[:, :7], axis=1)
+      print(json.dumps({"rows": rows, "second_group_us_median": {n: round(float(np.median(d[:, i])), 2) for i, n in enumerate(names)},
+                        "total": round(float(np.median(us[:, 6] - us[:, 0])), 2)}), flush=True)
+      del eng, X
+      torch.cuda.empty_cache()
+      continue
     names = ["setup g0", "setup g1", "barrier", "row loop (wave 0)", "wait for the other waves", "end of kernel"]
     d = np.diff(us[:, :7], axis=1)
     first = us[:, 0] < np.median(us[:, 0])    # the first round of workgroups
