@@ -138,6 +138,14 @@ int encoder_bwd_run(const oivae_shape_t& s, const oivae_tensors_t* grads, const 
                     const float* eps, float c, const float* prior_mu, const float* prior_sigma, int32_t prior_rows,
                     const float* mu_q, const float* sig_q, const float* ea, const float* dz, float* dpre,
                     double* bias_part, int n_bias, uint32_t* x3_img, uint32_t* rng, float* bwd_part, hipStream_t st);
+// atomicMax on a word that thousands of workgroups raise at about the same time (the maxima the fp16 kernels record
+// while they stream X): same-address atomics are served one by one, ~14 ns each, so the ones that cannot change the
+// word are skipped after a plain coherent load of it.  The word ends at the same maximum either way.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void atomic_max_if_larger(uint32_t* p, uint32_t v) {
+  if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) atomicMax(p, v);
+}
+#endif
 inline int enc_bias_blocks(int64_t B) { const int64_t bb = (B + 15) / 16; return (int)(bb > kBiasBlocks ? kBiasBlocks : bb); }
 // noalloc.hip: resolves the device address of the static scratch array for `device` (which must be current)
 int noalloc_scratch_setup(int device);

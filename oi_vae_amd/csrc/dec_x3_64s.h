@@ -600,7 +600,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
     }
   }
   __syncthreads();
-  if (tid == 0 && a.rng_seen != nullptr) atomicMax(a.rng_seen, flags[26]);
+  if (tid == 0 && a.rng_seen != nullptr) atomic_max_if_larger(a.rng_seen, flags[26]);
   float cs_gmu = 0.f, cs_gmu2 = 0.f, cs_da1 = 0.f;
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq) {   // fixed order

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(768, 1) void enc_x3_gemm(const float* __restrict__ 
     if (!BWD && rng != nullptr) {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o));
-      if (lane == 0) atomicMax(rng, __float_as_uint(xmax));  // non-negative floats order like their bit patterns
+      if (lane == 0) atomic_max_if_larger(rng, __float_as_uint(xmax));  // non-negative floats order like their bit patterns
     }
   } else {
     // ---------------- consumers ----------------
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(768, 1) void enc_h2_bwd_gemm(const float* __restric
     if (rng_seen != nullptr) {   // max|x| of what this wave streamed (every tile is stored at least once)
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o));
-      if (lane == 0) atomicMax(rng_seen, __float_as_uint(xmax));
+      if (lane == 0) atomic_max_if_larger(rng_seen, __float_as_uint(xmax));
     }
   } else {
     // ---------------- consumers (H2Consumer16) ----------------
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(768, 1) void enc_h2_fwd_gemm(const float* __restric
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o));
-    if (lane == 0) atomicMax(rng, __float_as_uint(xmax));
+    if (lane == 0) atomic_max_if_larger(rng, __float_as_uint(xmax));
   } else {
     // ---------------- consumers (H2Consumer16) ----------------
     const int wm = wave >> 1, wn = wave & 1;
