@@ -2474,10 +2474,15 @@ __global__ __launch_bounds__(256) void gated_zero_f32(float* __restrict__ p, int
 bool mfma_decoder_applies(const oivae_shape_t& s) {
   if (test_hooks().force_generic) return false;  // test hook: cross-check the two kernel families
   if (s.gen_type != OIVAE_GEN_MLP) return false;
+  // every dimension 32 or 64, one output width for all groups: the all-64 shape has its own kernels (dec_x3_64s and
+  // its cross-checks), the fifteen other combinations run the dimension-generic dec_mfma<K, H, M, DG> on the fp32
+  // matrix instruction
   const int dg = s.uniform_group_dim;
-  const bool all64 = (s.K == 64 && s.H == 64 && s.M == 64 && dg == 64);
-  const bool all32 = (s.K == 32 && s.H == 32 && s.M == 32 && dg == 32);
-  return all64 || all32;
+  auto ok = [](int v) { return v == 32 || v == 64; };
+  return ok(s.K) && ok(s.H) && ok(s.M) && ok(dg);
+}
+static inline bool dec_all64(const oivae_shape_t& s) {
+  return s.K == 64 && s.H == 64 && s.M == 64 && s.uniform_group_dim == 64;
 }
 
 template <int K, int H, int M, int DG>
@@ -2552,14 +2557,15 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   // (it also fetches the generator matrices 16 bytes per lane: parameters that are not 16-byte aligned take the bf16 pair)
   const bool aligned16 = ((reinterpret_cast<uintptr_t>(params->gen_W1) | reinterpret_cast<uintptr_t>(params->gen_W2) |
                            reinterpret_cast<uintptr_t>(params->Ws)) & 15) == 0;
-  const bool use_g = s.K == 64 && fits32 && aligned16 && (dec_env == nullptr || dec_env[0] == 'g' || dec_env[0] == 's');
+  const bool all64 = dec_all64(s);
+  const bool use_g = all64 && fits32 && aligned16 && (dec_env == nullptr || dec_env[0] == 'g' || dec_env[0] == 's');
   const bool use_s = use_g && (dec_env == nullptr || dec_env[0] == 's');   // dec_x3_64s: the same kernel on 16x16x32 instructions (default)
   uint32_t* rng = w.ranges;
   a.G = s.G;
   a.err = error_word_device();
   a.gate = nullptr;
   a.rng_seen = nullptr;
-  if (s.K == 64 && (use_x3 || use_g)) {
+  if (all64 && (use_x3 || use_g)) {
     if (!w.x3_z) return fail(OIVAE_E_WORKSPACE, "x3 decoder: no z image in the workspace");
     const int64_t zt = (N + 31) / 32;
     if (use_g) {
@@ -2600,15 +2606,23 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
     }
     OIVAE_LAUNCH_CHECK();
     rc = OIVAE_OK;
-  } else if (s.K == 64 && !force_v1 && N * (int64_t)s.K * 4 < (int64_t)1 << 32) {
+  } else if (all64 && !force_v1 && N * (int64_t)s.K * 4 < (int64_t)1 << 32) {
     const size_t lds = (size_t)(3 * 64 * 65 + 4 * 64 + 4 * 3 * 32 * 68) * sizeof(float);
     OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_mfma64_v4),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(dec_mfma64_v4, dim3((unsigned)s.G, (unsigned)chunks), dim3(256), lds, st, a);
     OIVAE_LAUNCH_CHECK();
     rc = OIVAE_OK;
-  } else if (s.K == 64) rc = launch_one<64, 64, 64, 64>(a, s.G, chunks, st);
-  else rc = launch_one<32, 32, 32, 32>(a, s.G, chunks, st);
+  } else {
+    // dimension-generic kernel: one instantiation per combination of 32 / 64
+    rc = fail(OIVAE_E_SHAPE, "MFMA decoder: unsupported dims K=%d H=%d M=%d D_g=%d", s.K, s.H, s.M, s.uniform_group_dim);
+#define OIVAE_DEC_ONE(KK, HH, MM, DD) \
+    if (s.K == KK && s.H == HH && s.M == MM && s.uniform_group_dim == DD) rc = launch_one<KK, HH, MM, DD>(a, s.G, chunks, st);
+#define OIVAE_DEC_KH(KK, HH) OIVAE_DEC_ONE(KK, HH, 32, 32) OIVAE_DEC_ONE(KK, HH, 32, 64) OIVAE_DEC_ONE(KK, HH, 64, 32) OIVAE_DEC_ONE(KK, HH, 64, 64)
+    OIVAE_DEC_KH(32, 32) OIVAE_DEC_KH(32, 64) OIVAE_DEC_KH(64, 32) OIVAE_DEC_KH(64, 64)
+#undef OIVAE_DEC_KH
+#undef OIVAE_DEC_ONE
+  }
   if (rc) return rc;
   if (chunks > 1)
     if (int rc2 = launch_slab_reduce(w.slab, L, chunks, grads, st)) return rc2;

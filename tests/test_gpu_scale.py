@@ -86,6 +86,40 @@ def test_mfma_kernels_agree_with_generic_kernels(tmp_path):
       assert err < 2e-5, (other, name, err)
 
 
+@pytest.mark.parametrize("K,H,M,dg", [(64, 32, 64, 32), (32, 64, 32, 64), (64, 64, 32, 64), (32, 32, 64, 64),
+                                      (64, 32, 32, 32), (32, 64, 64, 32), (64, 64, 64, 32)])
+def test_mixed_32_64_generators_on_the_matrix_decoder(K, H, M, dg):
+  """Two-layer generators whose four dimensions are 32 or 64 in any combination run dec_mfma<K, H, M, DG> (fp32 matrix
+  instruction, dz transposed); the shape-generic kernels on the same inputs are the check: ragged row count, two
+  samples, scalars 1e-5, every gradient tensor 2e-5 of its scale."""
+  G, B, S = 7, 150, 2   # 300 rows = 9.4 wave tiles
+  lib = _lib.load()
+  spec_eng = _engine(G, dg, K, H, M, seed=11)
+  import ctypes
+  assert lib.oivae_dz_layout(ctypes.byref(spec_eng._shape), B, S) == 1   # the matrix decoder's layout: this shape takes it
+  g = torch.Generator(device="cuda").manual_seed(6)
+  X = torch.rand(B, G * dg, generator=g, device="cuda")
+  eps = torch.randn(S, B, K, generator=g, device="cuda")
+  res = []
+  try:
+    for generic in (False, True):
+      _lib.set_test_hooks(OIVAE_FORCE_GENERIC="1" if generic else None)
+      eng = _engine(G, dg, K, H, M, seed=11)
+      out = eng.forward_backward(X, eps, 0.7)
+      torch.cuda.synchronize()
+      res.append((eng.flat_grads.clone(), out["scalars"].clone(), eng))
+  finally:
+    _lib.set_test_hooks(OIVAE_FORCE_GENERIC=None)
+  (ga, sa, eng), (gb, sb, _) = res
+  assert ((sa[:6] - sb[:6]).abs() / sb[:6].abs().clamp(min=1)).max().item() < 1e-5
+  for name in eng.seg_off:
+    o, n = eng.seg_off[name], eng.seg_numel[name]
+    if n == 0:
+      continue
+    err = ((ga[o:o + n] - gb[o:o + n]).abs().max() / gb[o:o + n].abs().max().clamp(min=1e-30)).item()
+    assert err < 2e-5, (name, err)
+
+
 def test_full_scale_batch_equals_mean_of_half_batches():
   G, dg, K = 1024, 64, 64
   B = 65536
