@@ -99,7 +99,7 @@ struct DecPlan {
 DecPlan plan_decoder(const oivae_shape_t& s, int64_t N);
 
 // flat (many-small-groups) decoder, flat_decoder.hip
-struct FlatLayout { int64_t oHc, oWc, oWk, oCt, oDzp, total; int splits; };
+struct FlatLayout { int64_t oHc, oWc, oWk, oCt, oDzp, oImgA, oImgB, oImgC, total; int splits; bool h2; };
 bool flat_decoder_applies(const oivae_shape_t& s, int64_t N);
 int64_t flat_decoder_floats(const oivae_shape_t& s, int64_t N, FlatLayout* L);
 int flat_decoder_blocks(const oivae_shape_t& s);

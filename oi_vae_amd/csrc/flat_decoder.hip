@@ -35,18 +35,43 @@ bool flat_decoder_applies(const oivae_shape_t& s, int64_t N) {
   return N * gh * 4 <= ((int64_t)1 << 30);  // Hc fits 1 GiB of workspace
 }
 
-// floats of workspace the flat path needs: Hc | Wc | Wk | Ct | dz partial images
+// The three products on two fp16 terms (round 2, last part): they have the encoder GEMMs' shapes -- a long-reduction
+// "NT" product (dz: N x K over G*H, = the encoder forward with X := dH, W := Wk), a weight-gradient "TN" product
+// (Ct: K x G*H over N, = the encoder backward with dpre := z) and Hc = z Wc^T (the forward kernel again, with the
+// latent dimension as its short reduction and the G*H columns as its 128-wide column tiles) -- so they run on
+// enc_h2_fwd_gemm / enc_h2_bwd_gemm (x3_encoder.hip) with their scale / guard / gated-repeat protocol, each product
+// family on its own 16 words of the workspace's ranges.  Wide-prox step: the three fp32-instruction GEMMs took 0.95
+// of 1.73 ms.  Shapes outside the h2 kernels' tiles, and OIVAE_ENC=bf16 / fp32, keep the fp32 matrix instruction.
+static bool flat_h2_applies(const oivae_shape_t& s, int64_t N) {
+  if (test_hooks().enc != 0) return false;
+  const int64_t gh = (int64_t)s.G * s.H;
+  return s.K % 128 == 0 && gh % 128 == 0 && N % 32 == 0;
+}
+static int flat_h2_dz_splits(const oivae_shape_t& s, int64_t N) {
+  const int64_t tiles = ((N + 127) / 128) * (s.K / 128);
+  const int64_t ktiles = (int64_t)s.G * s.H / 32;
+  int sp = 1;
+  while (sp < 32 && tiles * sp < 256 && ktiles / (sp * 2) >= 16) sp *= 2;
+  return sp;
+}
+
+// floats of workspace the flat path needs: Hc | Wc | Wk | Ct | dz partial images | h2 operand images
 int64_t flat_decoder_floats(const oivae_shape_t& s, int64_t N, FlatLayout* L) {
   const int64_t gh = (int64_t)s.G * s.H;
   FlatLayout l;
   int64_t off = 0;
   auto take = [&](int64_t n) { const int64_t o = off; off += (n + 63) / 64 * 64; return o; };
+  l.h2 = flat_h2_applies(s, N);
   l.oHc = take(N * gh);
   l.oWc = take(gh * s.K);
   l.oWk = take(gh * s.K);
   l.oCt = take(gh * s.K);
-  l.splits = mfma_gemm_nt_splits(N, (int)gh, s.K);
-  l.oDzp = take(l.splits > 1 ? (int64_t)l.splits * N * s.K : 0);
+  l.splits = l.h2 ? flat_h2_dz_splits(s, N) : mfma_gemm_nt_splits(N, (int)gh, s.K);
+  l.oDzp = take((l.splits > 1 || l.h2) ? (int64_t)l.splits * N * s.K : 0);
+  // images in two fp16 terms: 4 bytes per element of the operand (rows padded to 128); z^T sized as the encoder sizes dpre^T
+  l.oImgA = take(l.h2 ? gh * s.K : 0);
+  l.oImgC = take(l.h2 ? gh * s.K : 0);
+  l.oImgB = take(l.h2 ? (int64_t)s.K * ((N + 31) / 32) * 48 : 0);
   l.total = off;
   if (L) *L = l;
   return off;
@@ -209,9 +234,21 @@ int launch_decoder_flat(const oivae_shape_t& s, const oivae_tensors_t* params, c
   if (reinterpret_cast<uintptr_t>(z) & 15) return fail(OIVAE_E_ARG, "flat decoder: z must be 16-byte aligned");
   hipLaunchKernelGGL(flat_permute_ws, dim3(2048), dim3(256), 0, st, params->Ws, s.G, s.K, s.H, Wc, Wk);
   OIVAE_LAUNCH_CHECK();
-  // Hc = z Wc^T   (one partial image: the reduction length K is short)
-  if (mfma_gemm_nt_splits(N, s.K, GH) != 1) return fail(OIVAE_E_SHAPE, "flat decoder: unexpected split of the h product");
-  if (int rc = mfma_gemm_nt(z, N, s.K, Wc, GH, Hc, st)) return rc;
+  uint32_t* rngA = w.ranges + 16;   // dz and Ct products (X := dH)
+  uint32_t* rngC = w.ranges + 32;   // h product (X := z)
+  oivae_shape_t sa = s, sc = s;      // the encoder shapes the h2 launchers see: J = 2 K', reduction D'
+  sa.K = s.K / 2; sa.D = GH;
+  sc.K = GH / 2; sc.D = s.K;
+  if (L.h2) {
+    if ((reinterpret_cast<uintptr_t>(w.flat) & 15) != 0) return fail(OIVAE_E_ARG, "flat decoder: workspace must be 16-byte aligned");
+    oivae_tensors_t pc = {};
+    pc.enc_Wmu = Wc; pc.enc_Wsig = Wc + (int64_t)(GH / 2) * s.K;
+    if (int rc = launch_encoder_fwd_x3(sc, &pc, z, N, Hc, reinterpret_cast<uint32_t*>(w.flat + L.oImgC), rngC, 1, st)) return rc;
+  } else {
+    // Hc = z Wc^T   (one partial image: the reduction length K is short)
+    if (mfma_gemm_nt_splits(N, s.K, GH) != 1) return fail(OIVAE_E_SHAPE, "flat decoder: unexpected split of the h product");
+    if (int rc = mfma_gemm_nt(z, N, s.K, Wc, GH, Hc, st)) return rc;
+  }
   const float inv = 1.0f / ((float)S * (float)B);
   const dim3 grid((unsigned)flat_decoder_blocks(s));
   const bool th = s.gen_type == OIVAE_GEN_TANH_LINEAR;
@@ -227,6 +264,23 @@ int launch_decoder_flat(const oivae_shape_t& s, const oivae_tensors_t* params, c
   OIVAE_FLAT(4, 4) OIVAE_FLAT(4, 8) OIVAE_FLAT(8, 4) OIVAE_FLAT(8, 8)
 #undef OIVAE_FLAT
   OIVAE_LAUNCH_CHECK();
+  if (L.h2) {
+    // dz first: its forward-type kernel sees dH for the first time, verifies the scale it assumed and leaves max|dH|
+    // in its ranges; the weight-gradient kernel that follows scales dH by that
+    oivae_tensors_t pa = {};
+    pa.enc_Wmu = Wk; pa.enc_Wsig = Wk + (int64_t)(s.K / 2) * GH;
+    if (int rc = launch_encoder_fwd_x3(sa, &pa, Hc, N, dzp, reinterpret_cast<uint32_t*>(w.flat + L.oImgA), rngA, L.splits, st)) return rc;
+    launch_partial_sum(dzp, N * s.K, N * s.K, L.splits, dz, st);
+    OIVAE_LAUNCH_CHECK();
+    OIVAE_HIP_CHECK(hipMemsetAsync(rngA + 2, 0, 4, st));   // max|z|, and the backward kernel's own maximum and flag
+    OIVAE_HIP_CHECK(hipMemsetAsync(rngA + 8, 0, 8, st));
+    oivae_tensors_t ga = {};
+    ga.enc_Wmu = Ct; ga.enc_Wsig = Ct + (int64_t)(s.K / 2) * GH;
+    if (int rc = launch_encoder_bwd_x3(sa, &ga, Hc, z, N, reinterpret_cast<uint32_t*>(w.flat + L.oImgB), rngA, st)) return rc;
+    hipLaunchKernelGGL(flat_unpermute_dws, dim3(2048), dim3(256), 0, st, Ct, s.G, s.K, s.H, grads->Ws);
+    OIVAE_LAUNCH_CHECK();
+    return OIVAE_OK;
+  }
   // dWs: Ct[K, GH] = z^T dH, then back to [G, K, H]
   if (int rc = mfma_gemm_tn(z, Hc, N, s.K, GH, Ct, st)) return rc;
   hipLaunchKernelGGL(flat_unpermute_dws, dim3(2048), dim3(256), 0, st, Ct, s.G, s.K, s.H, grads->Ws);

@@ -362,7 +362,7 @@ def test_full_wide_prox_shape_whole_step():
   dW = eng.g["Ws"].cpu().numpy().copy()
   lr = 1e-4
   t = float(torch.linalg.vector_norm(eng.p["Ws"], dim=2).median())
-  eng.adam_step(1e-3)
+  eng.adam_step(1e-5)   # (32768 inputs moving by 1e-3 each in step would saturate the encoder's sigma head: a dead gradient)
   eng.sgd_prox_step(lr, t)
   torch.cuda.synchronize()
   pre = (W0.astype(np.float64) + np.float64(np.float32(-lr)) * dW.astype(np.float64)).astype(np.float32)
@@ -370,6 +370,34 @@ def test_full_wide_prox_shape_whole_step():
   assert np.array_equal(eng.p["Ws"].cpu().numpy().view(np.uint32), want.view(np.uint32))
   assert np.array_equal(eng.zero_mask.cpu().numpy(), wmask)
   assert 0.3 < wmask.mean() < 0.7
+  # second step, on the sparse state the proximal step left (half the rows of Ws exactly zero), with a few groups dead
+  # altogether, sigmas spread over two decades (the gradients of the pre-activations then span as much) and another
+  # batch whose maximum lies in another binade: the flat decoder on two fp16 terms (default), the flat decoder on the
+  # fp32 matrix instruction (OIVAE_ENC=fp32) and the shape-generic kernels must still agree
+  eng.p["Ws"][:5].zero_()
+  eng.p["log_sigma"].copy_(torch.log(10 ** (torch.rand(G * dg, generator=g, device="cuda") * 2 - 2.5)))
+  X2 = 3.0 * torch.rand(B, G * dg, generator=g, device="cuda")
+  res = {}
+  try:
+    for mode, hooks in (("generic", dict(OIVAE_FORCE_GENERIC="1")), ("flat_h2", {}), ("flat_fp32", dict(OIVAE_ENC="fp32"))):
+      _lib.set_test_hooks(OIVAE_FORCE_GENERIC=hooks.get("OIVAE_FORCE_GENERIC"), OIVAE_ENC=hooks.get("OIVAE_ENC"))
+      eng._ws_key = None
+      out = eng.forward_backward(X2, eps, 1.0)
+      torch.cuda.synchronize()
+      res[mode] = (eng.flat_grads.double().cpu().clone(), out["scalars"].double().cpu().clone())
+  finally:
+    _lib.set_test_hooks(OIVAE_FORCE_GENERIC=None, OIVAE_ENC=None)
+    eng._ws_key = None
+  b = res["generic"]
+  for mode in ("flat_h2", "flat_fp32"):
+    a = res[mode]
+    assert torch.isfinite(a[0]).all(), mode
+    assert float(((a[1][:6] - b[1][:6]).abs() / b[1][:6].abs().clamp(min=1.0)).max()) < 1e-5, mode
+    for name in eng.seg_off:
+      o, n = eng.seg_off[name], eng.seg_numel[name]
+      if n:
+        ga, gb = a[0][o:o + n], b[0][o:o + n]
+        assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-30, (mode, name)
 
 
 @pytest.mark.parametrize("typ,H,K", [("linear", 1, 10), ("tanh_linear", 8, 8), ("linear", 2, 16), ("tanh_linear", 4, 33),
