@@ -125,6 +125,7 @@ const TestHooks& test_hooks();
 void reload_test_hooks();
 bool x3_encoder_applies(const oivae_shape_t& s);
 int64_t x3_encoder_ws_bytes(const oivae_shape_t& s, int64_t B);
+uint32_t* h2_bwd_colmax(uint32_t* img, int J, int64_t B);   // the per-column maxima of dpre behind its image (rows_pad words)
 int64_t x3_encoder_bwd_img_bytes(const oivae_shape_t& s, int64_t B);  // image of dpre^T alone (0 when the x3 backward kernels do not apply)
 int x3_encoder_fwd_splits(const oivae_shape_t& s, int64_t B);
 bool x3_encoder_bwd_applies(const oivae_shape_t& s, int64_t B);

@@ -272,11 +272,12 @@ int launch_decoder_flat(const oivae_shape_t& s, const oivae_tensors_t* params, c
     if (int rc = launch_encoder_fwd_x3(sa, &pa, Hc, N, dzp, reinterpret_cast<uint32_t*>(w.flat + L.oImgA), rngA, L.splits, st)) return rc;
     launch_partial_sum(dzp, N * s.K, N * s.K, L.splits, dz, st);
     OIVAE_LAUNCH_CHECK();
-    OIVAE_HIP_CHECK(hipMemsetAsync(rngA + 2, 0, 4, st));   // max|z|, and the backward kernel's own maximum and flag
-    OIVAE_HIP_CHECK(hipMemsetAsync(rngA + 8, 0, 8, st));
+    OIVAE_HIP_CHECK(hipMemsetAsync(rngA + 8, 0, 8, st));   // the backward kernel's own maximum of dH and its flag
+    uint32_t* imgB = reinterpret_cast<uint32_t*>(w.flat + L.oImgB);
+    OIVAE_HIP_CHECK(hipMemsetAsync(h2_bwd_colmax(imgB, s.K, N), 0, sizeof(uint32_t) * s.K, st));   // column maxima of z
     oivae_tensors_t ga = {};
     ga.enc_Wmu = Ct; ga.enc_Wsig = Ct + (int64_t)(s.K / 2) * GH;
-    if (int rc = launch_encoder_bwd_x3(sa, &ga, Hc, z, N, reinterpret_cast<uint32_t*>(w.flat + L.oImgB), rngA, st)) return rc;
+    if (int rc = launch_encoder_bwd_x3(sa, &ga, Hc, z, N, imgB, rngA, st)) return rc;
     hipLaunchKernelGGL(flat_unpermute_dws, dim3(2048), dim3(256), 0, st, Ct, s.G, s.K, s.H, grads->Ws);
     OIVAE_LAUNCH_CHECK();
     return OIVAE_OK;

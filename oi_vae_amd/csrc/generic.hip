@@ -659,13 +659,14 @@ __global__ __launch_bounds__(256) void enc_bwd_pre(int64_t B, int K, int S, cons
 // one block per column j: the per-block partials are folded by a fixed-shape tree (deterministic)
 __global__ __launch_bounds__(256) void enc_bwd_bias_final(const double* __restrict__ bias_part, int nblk, int K,
                                                           float* __restrict__ dbmu, float* __restrict__ dbsig,
-                                                          uint32_t* __restrict__ rng) {
+                                                          uint32_t* __restrict__ rng, uint32_t* __restrict__ colmax) {
   __shared__ double sm[256];
   const int j = blockIdx.x;
   // the ranges the fp16 backward GEMM's helpers accumulate into with atomicMax start at zero (x3_encoder.hip:
   // [2] max|dpre|, [8] max|x| the kernel reads, [9] its redo flag); done here, one kernel ahead of them, instead of
   // two memsets of their own
   if (rng != nullptr && j == 0 && threadIdx.x == 0) { rng[2] = 0u; rng[8] = 0u; rng[9] = 0u; }
+  if (colmax != nullptr && threadIdx.x == 0) colmax[j] = 0u;   // ... and the per-column maxima of dpre (one block per column)
   double acc = 0.0;
   for (int b = threadIdx.x; b < nblk; b += 256) acc += bias_part[(int64_t)b * 2 * K + j];
   sm[threadIdx.x] = acc;
@@ -948,7 +949,8 @@ int oivae::encoder_bwd_run(const oivae_shape_t& s, const oivae_tensors_t* grads,
                      prior_mu, prior_sigma, prior_rows == 1 ? 0 : s.K, mu_q, sig_q, ea, dpre, bias_part);
   OIVAE_LAUNCH_CHECK();
   hipLaunchKernelGGL(enc_bwd_bias_final, dim3((unsigned)(2 * s.K)), dim3(256), 0, st, bias_part, n_bias,
-                     s.K, grads->enc_bmu, grads->enc_bsig, rng);
+                     s.K, grads->enc_bmu, grads->enc_bsig, rng,
+                     x3_encoder_bwd_applies(s, B) ? h2_bwd_colmax(x3_img, 2 * s.K, B) : (uint32_t*)nullptr);
   OIVAE_LAUNCH_CHECK();
   if (x3_encoder_bwd_applies(s, B)) {
     if (int rc = launch_encoder_bwd_x3(s, grads, X, dpre, B, x3_img, rng, st)) return rc;

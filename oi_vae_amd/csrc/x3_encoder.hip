@@ -334,15 +334,42 @@ __global__ __launch_bounds__(256) void absmax_f32(const float* __restrict__ v0, 
   }
 }
 
-// image of dpre^T in two fp16 terms: img[j][bt][s][piece][h][4 dwords], scaled by the power of two of rng[2]
+// max|P[:, j]| of P [B, J] (J a multiple of 128) for every column j, into colmax[j] (zeroed by the caller): the scales
+// of the dpre^T image are per COLUMN of dpre -- per row of the weight gradient, i.e. per encoder unit -- so that a
+// unit whose gradient lies far below the others' (a saturated sigma head: 1e-15 beside 1e+7, seen in
+// tests/test_gpu_scale.py's wide-prox state) keeps its own 22 bits instead of being flushed by the matrix maximum.
+// Thread = column (tid mod 128) + 128 c, two row lanes per workgroup; one atomic per column and workgroup, skipped
+// when the word already holds as much.
+__global__ __launch_bounds__(256) void absmax_cols_f32(const float* __restrict__ P, int64_t B, int J,
+                                                       uint32_t* __restrict__ colmax) {
+  __shared__ float part[128];
+  const int jl = threadIdx.x & 127, rl = threadIdx.x >> 7;
+  const int64_t rpb = (B + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = (r0 + rpb < B) ? r0 + rpb : B;
+  for (int jc = 0; jc < J; jc += 128) {
+    float m = 0.f;
+    int64_t r = r0 + rl;
+    for (; r + 6 < r1; r += 8) {   // four rows in flight per lane
+      const float a0 = P[r * J + jc + jl], a1 = P[(r + 2) * J + jc + jl], a2 = P[(r + 4) * J + jc + jl], a3 = P[(r + 6) * J + jc + jl];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(a0), fabsf(a1))), fmaxf(fabsf(a2), fabsf(a3)));
+    }
+    for (; r < r1; r += 2) m = fmaxf(m, fabsf(P[r * J + jc + jl]));
+    __syncthreads();
+    if (rl == 1) part[jl] = m;
+    __syncthreads();
+    if (rl == 0) atomic_max_if_larger(colmax + jc + jl, __float_as_uint(fmaxf(m, part[jl])));
+  }
+}
+
+// image of dpre^T in two fp16 terms: img[j][bt][s][piece][h][4 dwords], row j scaled by the power of two of colmax[j]
 __global__ __launch_bounds__(256) void h2_split_cols(const float* __restrict__ P, int64_t B, int J, int rows_pad, int BT,
-                                                     uint32_t* __restrict__ img, const uint32_t* __restrict__ rng) {
+                                                     uint32_t* __restrict__ img, const uint32_t* __restrict__ colmax) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)rows_pad * BT * 4;
   if (i >= total) return;
-  float sc, inv;
-  h2_scale_of(rng[2], &sc, &inv);
   const int j = (int)(i % rows_pad);
+  float sc, inv;
+  h2_scale_of(colmax[j], &sc, &inv);
   const int64_t c = i / rows_pad;
   const int64_t bt = c >> 2;
   const int s = (int)(c >> 1) & 1, h = (int)c & 1;
@@ -493,7 +520,8 @@ __global__ __launch_bounds__(768, 1) void enc_h2_bwd_gemm(const float* __restric
                                                           const uint32_t* __restrict__ Pimg, int BT,
                                                           float* __restrict__ out0, float* __restrict__ out1,
                                                           const uint32_t* __restrict__ rng, uint32_t* __restrict__ rng_seen,
-                                                          const uint32_t* __restrict__ gate) {
+                                                          const uint32_t* __restrict__ gate,
+                                                          const uint32_t* __restrict__ colmax) {
   if (gate != nullptr && *gate == 0) return;  // second launch: only if the guard rejected the first one's scale of X
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint32_t* lds = reinterpret_cast<uint32_t*>(smem_raw);  // [2][kH2Buf]
@@ -503,9 +531,8 @@ __global__ __launch_bounds__(768, 1) void enc_h2_bwd_gemm(const float* __restric
   const int j0 = blockIdx.y * 128;
   const int T = (int)(B / 32);
   const int Tr = (T + 3) & ~3;
-  float sx, ix, sp, ip;
+  float sx, ix;
   h2_scale_of(rng[0], &sx, &ix);
-  h2_scale_of(rng[2], &sp, &ip);
 
   if (wave >= 8) {
     // ---------------- producers of the dpre^T image ----------------
@@ -597,6 +624,8 @@ __global__ __launch_bounds__(768, 1) void enc_h2_bwd_gemm(const float* __restric
 #pragma unroll
       for (int Jb = 0; Jb < 4; ++Jb) {
         const int col = j0 + wn * 64 + H2Consumer16::out_col(Jb, lane);
+        float sp, ip;
+        h2_scale_of(colmax[col], &sp, &ip);   // (the image and colmax have rows_pad >= j0 + 128 rows)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int mrow = wm * 64 + H2Consumer16::out_row(I, i, lane);
@@ -841,6 +870,11 @@ int64_t x3_encoder_ws_bytes(const oivae_shape_t& s, int64_t B) {
   return (int64_t)x3_rows_pad(2 * s.K) * (kt > bt ? kt : bt) * 48 * 4;  // 3 x bf16 per element of the larger image
 }
 
+// the per-column maxima of dpre (rows_pad words) sit behind the fp16 image of dpre^T (rows_pad * BT * 32 words) inside
+// the image's allocation, which is sized for the three-term bf16 image (48 words per row and 32-row tile)
+uint32_t* h2_bwd_colmax(uint32_t* img, int J, int64_t B) {
+  return img + (int64_t)x3_rows_pad(J) * ((B + 31) / 32) * 32;
+}
 int64_t x3_encoder_bwd_img_bytes(const oivae_shape_t& s, int64_t B) {
   if (!x3_encoder_bwd_applies(s, B)) return 0;
   return (int64_t)x3_rows_pad(2 * s.K) * ((B + 31) / 32) * 48 * 4;
@@ -917,11 +951,17 @@ int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, 
   const int BT = (int)((B + 31) / 32);
   const int64_t chunks = (int64_t)Jp * BT * 4;
   if (h2_enabled()) {
-    // rng[2], rng[8], rng[9] were zeroed by enc_bwd_bias_final, the kernel before this one (generic.hip: encoder_bwd_run)
-    hipLaunchKernelGGL(absmax_f32, dim3(absmax_blocks(B * (int64_t)J, 1), 1), dim3(256), 0, st, dpre, (const float*)nullptr,
-                       B * (int64_t)J, rng + 2);
+    // rng[8], rng[9] and the Jp column maxima behind the image were zeroed by the caller (generic.hip: encoder_bwd_run
+    // has enc_bwd_bias_final, the kernel before this one, do it; flat_decoder.hip uses memsets)
+    uint32_t* colmax = h2_bwd_colmax(img, J, B);
+    {
+      int64_t nb = (B + 63) / 64;
+      if (nb > 256) nb = 256;
+      hipLaunchKernelGGL(absmax_cols_f32, dim3((unsigned)nb), dim3(256), 0, st, dpre, B, J, colmax);
+    }
     OIVAE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(h2_split_cols, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, dpre, B, J, Jp, BT, img, rng);
+    hipLaunchKernelGGL(h2_split_cols, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, dpre, B, J, Jp, BT, img,
+                       (const uint32_t*)colmax);
     OIVAE_LAUNCH_CHECK();
     const size_t lds = sizeof(uint32_t) * 2 * kH2Buf;
     OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_h2_bwd_gemm),
@@ -930,12 +970,12 @@ int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, 
     // X is scaled by the max|X| the ranges hold (the forward call of this step recorded it); the kernel records what
     // it streams itself and the guard repeats it with that maximum if the two powers of two differ
     hipLaunchKernelGGL(enc_h2_bwd_gemm, grid, dim3(768), lds, st, X, B, s.D, J, img, BT, grads->enc_Wmu, grads->enc_Wsig,
-                       (const uint32_t*)rng, rng + 8, (const uint32_t*)nullptr);
+                       (const uint32_t*)rng, rng + 8, (const uint32_t*)nullptr, (const uint32_t*)colmax);
     OIVAE_LAUNCH_CHECK();
     launch_range_guard(rng, 8, 9, st);
     OIVAE_LAUNCH_CHECK();
     hipLaunchKernelGGL(enc_h2_bwd_gemm, grid, dim3(768), lds, st, X, B, s.D, J, img, BT, grads->enc_Wmu, grads->enc_Wsig,
-                       (const uint32_t*)rng, (uint32_t*)nullptr, (const uint32_t*)(rng + 9));
+                       (const uint32_t*)rng, (uint32_t*)nullptr, (const uint32_t*)(rng + 9), (const uint32_t*)colmax);
     OIVAE_LAUNCH_CHECK();
     return OIVAE_OK;
   }

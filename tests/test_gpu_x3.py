@@ -274,6 +274,38 @@ def test_fp16_backward_weight_gradient_is_fp32_grade():
     _check(err, float(want.abs().max()))
 
 
+def test_fp16_backward_scales_every_encoder_unit_by_its_own_gradient():
+  """The image of dpre^T is scaled per column of dpre (absmax_cols_f32): an encoder unit whose gradient lies many
+  orders below the others' -- a saturated sigma head -- keeps fp32-grade accuracy relative to ITS OWN row of the weight
+  gradient.  Rows of dz from 1 down to 1e-30 (and one all-zero row) against float64, row by row."""
+  from oi_vae_amd import _lib
+  B, D, K = 2048, 4096, 64
+  eng, g = _engine(D, K, seed=23)
+  X = torch.rand(B, D, generator=g, device="cuda")
+  zeros, ones = torch.zeros(B, K, device="cuda"), torch.ones(B, K, device="cuda")
+  eps = torch.zeros(1, B, K, device="cuda")
+  pm, ps = torch.zeros(1, K, device="cuda"), torch.ones(1, K, device="cuda")
+  fac = 10.0 ** (-torch.arange(K, device="cuda", dtype=torch.float32) * (30.0 / (K - 1)))
+  fac[7] = 0.0
+  dzT = torch.randn(K, B, generator=g, device="cuda") * fac[:, None]
+  want = (dzT.double() @ X.double()).cpu()
+  _mode("x3")
+  _encoder_fwd(eng, X, eps)
+  ws = eng._workspace(B, 1)
+  eng.flat_grads.fill_(float("nan"))
+  _lib.check(eng.lib.oivae_encoder_bwd_f32(ctypes.byref(eng._shape), ctypes.byref(eng._gt), X.data_ptr(), B, 1,
+             eps.data_ptr(), 1.0, pm.data_ptr(), ps.data_ptr(), 1, zeros.data_ptr(), ones.data_ptr(), ones.data_ptr(),
+             dzT.data_ptr(), ws.data_ptr(), eng._ws_bytes, eng._stream()), "encoder_bwd")
+  torch.cuda.synchronize()
+  got = eng.g["enc_Wmu"].double().cpu()
+  assert torch.isfinite(got).all()
+  row_scale = want.abs().max(dim=1).values
+  row_err = (got - want).abs().max(dim=1).values
+  assert float(row_err[7]) == 0.0 and float(row_scale[7]) == 0.0
+  live = row_scale > 0
+  assert float((row_err[live] / row_scale[live]).max()) < 5e-6, (row_err / row_scale.clamp(min=1e-300)).tolist()
+
+
 @pytest.mark.parametrize("case", ["plain", "mixed_sigma", "large_x", "small_latent", "big_weights", "odd_groups",
                                   "dead_group", "huge_w2_row", "x_span", "saturated_tanh", "x_zero"])
 def test_fp16_chain_decoder_step_against_float64(case):
