@@ -132,7 +132,9 @@ bool x3_encoder_bwd_applies(const oivae_shape_t& s, int64_t B);
 int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X, const float* dpre,
                           int64_t B, uint32_t* img, uint32_t* rng, hipStream_t st);
 int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params, const float* X, int64_t B,
-                          float* pre, uint32_t* wimg, uint32_t* rng, int splits, hipStream_t st);
+                          float* pre, uint32_t* wimg, uint32_t* rng, int splits, hipStream_t st,
+                          bool image_ready = false);   // image_ready: wimg and rng[1] (max|W|) were prepared by the caller
+void launch_absmax_f32(const float* v, int64_t n, uint32_t* out, hipStream_t st);   // atomicMax into *out (caller zeroes it)
 // the kernel sequence of oivae_encoder_bwd_f32 on explicit scratch regions (generic.hip): dpre [B, 2K] floats,
 // bias_part [n_bias, 2K] doubles, x3_img x3_encoder_bwd_img_bytes (or the workspace's larger image), rng 64 words
 int encoder_bwd_run(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X, int64_t B, int32_t S,

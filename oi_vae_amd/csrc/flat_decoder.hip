@@ -12,6 +12,7 @@
 // so the three big products run on the fp32 matrix cores and dz needs no atomics (the step becomes bit-reproducible).
 // Roofline: the GEMMs are MFMA-bound (3 * 2*N*K*G*H flops), the group kernel HBM-bound (one read and one write of Hc).
 #include "common.h"
+#include "x3_split.h"
 
 #include <stdlib.h>
 
@@ -90,6 +91,64 @@ __global__ __launch_bounds__(256) void flat_permute_ws(const float* __restrict__
     const float v = Ws[i];
     Wc[(g * H + h) * K + k] = v;
     Wk[(int64_t)k * gh + g * H + h] = v;
+  }
+}
+
+// Both weight images of the h2 path straight from Ws [G, K, H], in the layout h2_split_rows (x3_encoder.hip) gives an
+// image: per (row, 32 reduction slots) 32 dwords = two sub-steps of [hi 8 halves | hi 8 halves | lo | lo]:
+//   imgA: row k, reduction over the flattened (g, h) (the dz product's W := Wk),
+//   imgC: row (g, h), reduction over k (the h product's W := Wc),
+// scaled by the power of two of max|Ws| (maxw[0]; also copied to maxw_copy[0] for the other product's ranges).
+// A workgroup owns 32 / H consecutive groups = one 32-slot reduction tile of imgA for every k, and 32 rows of imgC.
+template <int H>
+__global__ __launch_bounds__(256) void flat_split_ws(const float* __restrict__ Ws, int G, int K,
+                                                     uint32_t* __restrict__ imgA, uint32_t* __restrict__ imgC,
+                                                     const uint32_t* __restrict__ maxw, uint32_t* __restrict__ maxw_copy) {
+  constexpr int GB = 32 / H, LH = H + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* tile = reinterpret_cast<float*>(smem_raw);   // [GB][K][H + 1]
+  const int tid = threadIdx.x;
+  const int g0 = blockIdx.x * GB;
+  if (blockIdx.x == 0 && tid == 0) maxw_copy[0] = maxw[0];
+  float sc, inv;
+  h2_scale_of(maxw[0], &sc, &inv);
+  const int per = K * H;
+  for (int i = tid; i < GB * per; i += 256) {
+    const int gl = i / per, rem = i - gl * per;
+    const int k = rem / H, h = rem - k * H;
+    tile[(gl * K + k) * LH + h] = (g0 + gl < G) ? Ws[(int64_t)(g0 + gl) * per + rem] * sc : 0.f;
+  }
+  __syncthreads();
+  const int KT_A = G * H / 32, KT_C = K / 32;
+  auto put = [](uint32_t* dst, const float (&v)[8]) {
+    x3_u32x4 Q[2];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const Split2 q = split2_pair(v[2 * e], v[2 * e + 1]);
+      Q[0][e] = q.h; Q[1][e] = q.l;
+    }
+    *reinterpret_cast<x3_u32x4*>(dst) = Q[0];
+    *reinterpret_cast<x3_u32x4*>(dst + 8) = Q[1];
+  };
+  for (int it = tid; it < K * 4; it += 256) {   // imgA: (row k, chunk c of this workgroup's reduction tile)
+    const int k = it >> 2, c = it & 3;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r = 8 * c + e, gl = r / H, h = r - gl * H;
+      v[e] = tile[(gl * K + k) * LH + h];
+    }
+    put(imgA + (((int64_t)k * KT_A + blockIdx.x) * 2 + (c >> 1)) * 16 + 4 * (c & 1), v);
+  }
+  const int cpr = K / 8;   // chunks per row of imgC
+  for (int it = tid; it < 32 * cpr; it += 256) {   // imgC: (row rl of this workgroup's 32, chunk c over k)
+    const int rl = it / cpr, c = it - rl * cpr;
+    const int gl = rl / H, h = rl - gl * H;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[(gl * K + 8 * c + e) * LH + h];
+    const int64_t row = (int64_t)blockIdx.x * 32 + rl;
+    put(imgC + ((row * KT_C + (c >> 2)) * 2 + ((c >> 1) & 1)) * 16 + 4 * (c & 1), v);
   }
 }
 
@@ -232,8 +291,10 @@ int launch_decoder_flat(const oivae_shape_t& s, const oivae_tensors_t* params, c
   float* Ct = w.flat + L.oCt;
   float* dzp = w.flat + L.oDzp;
   if (reinterpret_cast<uintptr_t>(z) & 15) return fail(OIVAE_E_ARG, "flat decoder: z must be 16-byte aligned");
-  hipLaunchKernelGGL(flat_permute_ws, dim3(2048), dim3(256), 0, st, params->Ws, s.G, s.K, s.H, Wc, Wk);
-  OIVAE_LAUNCH_CHECK();
+  if (!L.h2) {
+    hipLaunchKernelGGL(flat_permute_ws, dim3(2048), dim3(256), 0, st, params->Ws, s.G, s.K, s.H, Wc, Wk);
+    OIVAE_LAUNCH_CHECK();
+  }
   uint32_t* rngA = w.ranges + 16;   // dz and Ct products (X := dH)
   uint32_t* rngC = w.ranges + 32;   // h product (X := z)
   oivae_shape_t sa = s, sc = s;      // the encoder shapes the h2 launchers see: J = 2 K', reduction D'
@@ -241,9 +302,27 @@ int launch_decoder_flat(const oivae_shape_t& s, const oivae_tensors_t* params, c
   sc.K = GH / 2; sc.D = s.K;
   if (L.h2) {
     if ((reinterpret_cast<uintptr_t>(w.flat) & 15) != 0) return fail(OIVAE_E_ARG, "flat decoder: workspace must be 16-byte aligned");
+    // max|Ws| once, both weight images in one pass over Ws (no fp32 copies of the permuted matrices on this path)
+    uint32_t* imgA = reinterpret_cast<uint32_t*>(w.flat + L.oImgA);
+    uint32_t* imgC = reinterpret_cast<uint32_t*>(w.flat + L.oImgC);
+    OIVAE_HIP_CHECK(hipMemsetAsync(rngC + 1, 0, 4, st));
+    launch_absmax_f32(params->Ws, (int64_t)s.G * s.K * s.H, rngC + 1, st);
+    OIVAE_LAUNCH_CHECK();
+    {
+      const int gb = 32 / s.H;
+      const unsigned blocks = (unsigned)((s.G + gb - 1) / gb);
+      const size_t lds = sizeof(float) * (size_t)gb * s.K * (s.H + 1);
+      if (s.H == 8) {
+        OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flat_split_ws<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(flat_split_ws<8>, dim3(blocks), dim3(256), lds, st, params->Ws, s.G, s.K, imgA, imgC, (const uint32_t*)(rngC + 1), rngA + 1);
+      } else {
+        OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&flat_split_ws<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(flat_split_ws<4>, dim3(blocks), dim3(256), lds, st, params->Ws, s.G, s.K, imgA, imgC, (const uint32_t*)(rngC + 1), rngA + 1);
+      }
+      OIVAE_LAUNCH_CHECK();
+    }
     oivae_tensors_t pc = {};
-    pc.enc_Wmu = Wc; pc.enc_Wsig = Wc + (int64_t)(GH / 2) * s.K;
-    if (int rc = launch_encoder_fwd_x3(sc, &pc, z, N, Hc, reinterpret_cast<uint32_t*>(w.flat + L.oImgC), rngC, 1, st)) return rc;
+    if (int rc = launch_encoder_fwd_x3(sc, &pc, z, N, Hc, imgC, rngC, 1, st, true)) return rc;
   } else {
     // Hc = z Wc^T   (one partial image: the reduction length K is short)
     if (mfma_gemm_nt_splits(N, s.K, GH) != 1) return fail(OIVAE_E_SHAPE, "flat decoder: unexpected split of the h product");
@@ -268,8 +347,7 @@ int launch_decoder_flat(const oivae_shape_t& s, const oivae_tensors_t* params, c
     // dz first: its forward-type kernel sees dH for the first time, verifies the scale it assumed and leaves max|dH|
     // in its ranges; the weight-gradient kernel that follows scales dH by that
     oivae_tensors_t pa = {};
-    pa.enc_Wmu = Wk; pa.enc_Wsig = Wk + (int64_t)(s.K / 2) * GH;
-    if (int rc = launch_encoder_fwd_x3(sa, &pa, Hc, N, dzp, reinterpret_cast<uint32_t*>(w.flat + L.oImgA), rngA, L.splits, st)) return rc;
+    if (int rc = launch_encoder_fwd_x3(sa, &pa, Hc, N, dzp, reinterpret_cast<uint32_t*>(w.flat + L.oImgA), rngA, L.splits, st, true)) return rc;
     launch_partial_sum(dzp, N * s.K, N * s.K, L.splits, dz, st);
     OIVAE_LAUNCH_CHECK();
     OIVAE_HIP_CHECK(hipMemsetAsync(rngA + 8, 0, 8, st));   // the backward kernel's own maximum of dH and its flag

@@ -902,8 +902,12 @@ static inline unsigned absmax_blocks(int64_t n, int arrays) { const int64_t b = 
 static inline bool h2_enabled() { return test_hooks().enc != 'b'; }
 void launch_range_guard(uint32_t* rng, int seen, int flag, hipStream_t st);  // mfma_decoder.hip
 
+void launch_absmax_f32(const float* v, int64_t n, uint32_t* out, hipStream_t st) {
+  hipLaunchKernelGGL(absmax_f32, dim3(absmax_blocks(n, 1), 1), dim3(256), 0, st, v, (const float*)nullptr, n, out);
+}
+
 int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params, const float* X, int64_t B,
-                          float* pre, uint32_t* wimg, uint32_t* rng, int splits, hipStream_t st) {
+                          float* pre, uint32_t* wimg, uint32_t* rng, int splits, hipStream_t st, bool image_ready) {
   if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(wimg) & 15))
     return fail(OIVAE_E_ARG, "x3 encoder: X and the workspace must be 16-byte aligned");
   const int J = 2 * s.K, Jp = x3_rows_pad(J), KT = x3_ktiles(s.D);
@@ -913,14 +917,18 @@ int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int klen = ((KT + splits - 1) / splits) * 32;
   const dim3 grid((unsigned)((B + 127) / 128), (unsigned)(Jp / 128), (unsigned)splits);
-  OIVAE_HIP_CHECK(hipMemsetAsync(rng, 0, 16, st));   // [0] max|X| of this call, [1] max|W|, [2] max|dpre|, [3] redo flag
+  if (image_ready && !h2_enabled()) return fail(OIVAE_E_ARG, "x3 encoder: a prepared image needs the fp16 kernels");
+  // [0] max|X| of this call, [1] max|W|, [2] unused here, [3] redo flag (a prepared image comes with its rng[1])
+  OIVAE_HIP_CHECK(hipMemsetAsync(rng, 0, image_ready ? 4 : 16, st));
   if (h2_enabled()) {
-    hipLaunchKernelGGL(absmax_f32, dim3(absmax_blocks((int64_t)s.K * s.D, 2), 2), dim3(256), 0, st, params->enc_Wmu,
-                       params->enc_Wsig, (int64_t)s.K * s.D, rng + 1);
-    OIVAE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(h2_split_rows, dim3((unsigned)(((chunks + 1) / 2 + 255) / 256)), dim3(256), 0, st, params->enc_Wmu,
-                       params->enc_Wsig, s.K, J, s.D, Jp, KT, wimg, rng);
-    OIVAE_LAUNCH_CHECK();
+    if (!image_ready) {
+      hipLaunchKernelGGL(absmax_f32, dim3(absmax_blocks((int64_t)s.K * s.D, 2), 2), dim3(256), 0, st, params->enc_Wmu,
+                         params->enc_Wsig, (int64_t)s.K * s.D, rng + 1);
+      OIVAE_LAUNCH_CHECK();
+      hipLaunchKernelGGL(h2_split_rows, dim3((unsigned)(((chunks + 1) / 2 + 255) / 256)), dim3(256), 0, st, params->enc_Wmu,
+                         params->enc_Wsig, s.K, J, s.D, Jp, KT, wimg, rng);
+      OIVAE_LAUNCH_CHECK();
+    }
     const size_t lds2 = sizeof(uint32_t) * 2 * kH2Buf;
     OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_h2_fwd_gemm),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
@@ -955,8 +963,8 @@ int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, 
     // has enc_bwd_bias_final, the kernel before this one, do it; flat_decoder.hip uses memsets)
     uint32_t* colmax = h2_bwd_colmax(img, J, B);
     {
-      int64_t nb = (B + 63) / 64;
-      if (nb > 256) nb = 256;
+      int64_t nb = (B + 15) / 16;   // a chain of dependent loads per lane: short chains, many workgroups
+      if (nb > 512) nb = 512;
       hipLaunchKernelGGL(absmax_cols_f32, dim3((unsigned)nb), dim3(256), 0, st, dpre, B, J, colmax);
     }
     OIVAE_LAUNCH_CHECK();
