@@ -86,8 +86,8 @@ def test_mfma_kernels_agree_with_generic_kernels(tmp_path):
       assert err < 2e-5, (other, name, err)
 
 
-@pytest.mark.parametrize("K,H,M,dg", [(64, 32, 64, 32), (32, 64, 32, 64), (64, 64, 32, 64), (32, 32, 64, 64),
-                                      (64, 32, 32, 32), (32, 64, 64, 32), (64, 64, 64, 32)])
+@pytest.mark.parametrize("K,H,M,dg", [(k, h, m, d) for k in (32, 64) for h in (32, 64) for m in (32, 64) for d in (32, 64)
+                                      if (k, h, m, d) not in ((64, 64, 64, 64), (32, 32, 32, 32))])
 def test_mixed_32_64_generators_on_the_matrix_decoder(K, H, M, dg):
   """Two-layer generators whose four dimensions are 32 or 64 in any combination run dec_mfma<K, H, M, DG> (fp32 matrix
   instruction, dz transposed); the shape-generic kernels on the same inputs are the check: ragged row count, two
