@@ -282,6 +282,74 @@ __global__ __launch_bounds__(kProxLdsThreads, 1) void prox_rows_vec_lds(float* _
   }
 }
 
+// ---- path D: H >= 512, where ATen's row sum cascades (oracle/prox_oracle.c: oivae_oracle_row_sumsq) ----
+// The CPU kernel's sum is 32 independent chains -- 4 vector accumulators x 8 lanes, chain (k, l) taking elements
+// 32 i + 8 k + l, i = 0, 1, ... -- each with the same cascade: every 16 steps level 0 is added into level 1 and cleared,
+// every 256 steps level 1 into level 2, every 4096 level 2 into level 3.  32 threads share a row, one chain each (the
+// reads of a step are one contiguous 128 bytes); then the levels fold into level 0, the vectors left over behind the
+// last full step go to accumulator 0's lanes, accumulators 1..3 are added to accumulator 0 in order, and one thread
+// adds the scalar tail and the eight lanes left to right.  A second pass over the row applies the threshold.
+template <bool SGD>
+__global__ __launch_bounds__(256) void prox_rows_wide(float* __restrict__ Ws, const float* __restrict__ dWs,
+                                                      int64_t rows, int H, float neg_lr, float t, int do_prox,
+                                                      uint8_t* __restrict__ mask, float* __restrict__ norms,
+                                                      const uint16_t* __restrict__ tab) {
+  const int sub = threadIdx.x & 31;                                    // chain: accumulator k = sub / 8, lane l = sub % 8
+  const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const bool live = r < rows;                                           // uniform per group of 32
+  const int64_t rr = live ? r : rows - 1;
+  float* w = Ws + rr * H;
+  const float* g = SGD ? dWs + rr * H : nullptr;
+  auto ld = [&](int i) -> float {
+    float v = w[i];
+    if (SGD) v = __builtin_fmaf(neg_lr, g[i], v);
+    return v;
+  };
+  const int V = H / 8, nq = V / 4;
+  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+  int i = 0;
+  while (i + 16 <= nq) {
+    for (int j = 0; j < 16; ++j, ++i) { const float a = ld(32 * i + sub); p0 = p0 + a * a; }
+    p1 = p1 + p0; p0 = 0.f;
+    if ((i & (15 << 4)) == 0) {
+      p2 = p2 + p1; p1 = 0.f;
+      if ((i & (15 << 8)) == 0) { p3 = p3 + p2; p2 = 0.f; }
+    }
+  }
+  for (; i < nq; ++i) { const float a = ld(32 * i + sub); p0 = p0 + a * a; }
+  p0 = p0 + p1; p0 = p0 + p2; p0 = p0 + p3;
+  if (sub < 8)
+    for (int v = nq * 4; v < V; ++v) { const float a = ld(v * 8 + sub); p0 = p0 + a * a; }
+  const int base = (threadIdx.x & 63) & 32;   // first lane of this row's 32 inside the wave
+  {
+    const float q1 = __shfl(p0, base + 8 + (sub & 7)), q2 = __shfl(p0, base + 16 + (sub & 7)), q3 = __shfl(p0, base + 24 + (sub & 7));
+    p0 = p0 + q1; p0 = p0 + q2; p0 = p0 + q3;   // meaningful in the threads of accumulator 0 (sub < 8)
+  }
+  float acc = 0.f;
+  for (int h = V * 8; h < H; ++h) { const float a = ld(h); acc = acc + a * a; }   // (every thread: the tail is under 8 elements)
+#pragma unroll
+  for (int l = 0; l < 8; ++l) acc = acc + __shfl(p0, base + l);
+  const float n = mkl_sqrtf_dev(acc, tab);
+  float den, sc;
+  prox_scales(n, t, den, sc);
+  bool allzero = true;
+  if (live) {
+    for (int h = sub; h < H; h += 32) {
+      float v = ld(h);
+      if (do_prox) { v = v / den; v = v * sc; }
+      w[h] = v;
+      allzero = allzero && (v == 0.0f);
+    }
+  }
+  int az = allzero ? 1 : 0;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) az &= __shfl_xor(az, o);
+  if (live && sub == 0) {
+    if (mask) mask[r] = (uint8_t)az;
+    if (norms) norms[r] = n;
+  }
+}
+
 // ---- column form: FirstLayerSparseDecoder.proximal_step (/root/reference/lib/models.py:65-71) ----
 // The G latent-to-group maps (nn.Linear(K, H_g).weight, [H_g, K]) are stacked on rows; a column of one map
 // is soft-thresholded by its norm over dim 0.  One thread per (map, column): consecutive threads read
@@ -399,7 +467,11 @@ static int launch_prox(float* Ws, const float* dWs, int64_t rows, int H, float l
   else if (aligned && H == 32) OIVAE_PROX_VEC(4)
   else if (aligned && H == 64) OIVAE_PROX_VEC(8)
   else if (aligned && H == 128) OIVAE_PROX_VEC(16)
-  else {
+  else if (H >= 512) {
+    const unsigned blocks = (unsigned)((rows * 32 + 255) / 256);
+    hipLaunchKernelGGL((prox_rows_wide<SGD>), dim3(blocks), dim3(256), 0, st, Ws, dWs, rows, H,
+                       neg_lr, t, do_prox, mask, norms, tab);
+  } else {
     const unsigned blocks = (unsigned)((rows + 255) / 256);
     hipLaunchKernelGGL((prox_rows_scalar<SGD>), dim3(blocks), dim3(256), 0, st, Ws, dWs, rows, H,
                        neg_lr, t, do_prox, mask, norms, tab);
@@ -416,8 +488,8 @@ using namespace oivae;
 extern "C" int oivae_prox_f32(float* Ws, int64_t rows, int32_t H, float t, uint8_t* zero_mask,
                               float* row_norms, void* stream) {
   if (!Ws || rows < 0) return fail(OIVAE_E_ARG, "oivae_prox_f32: null Ws or negative rows");
-  if (H < 1 || H >= 512)
-    return fail(OIVAE_E_SHAPE, "oivae_prox_f32: H=%d outside [1,512) (the reference's row-sum order is pinned only there)", H);
+  if (H < 1 || H > (1 << 20))
+    return fail(OIVAE_E_SHAPE, "oivae_prox_f32: H=%d outside [1, 2^20] (the reference's row-sum order is pinned only there)", H);
   if (rows * 2 / 256 > 0x7fffffffLL) return fail(OIVAE_E_SHAPE, "oivae_prox_f32: too many rows");
   return launch_prox<false>(Ws, nullptr, rows, H, 0.f, t, 1, zero_mask, row_norms, (hipStream_t)stream);
 }
@@ -426,8 +498,8 @@ extern "C" int oivae_sgd_prox_f32(float* Ws, const float* dWs, int64_t rows, int
                                   float t, int32_t do_prox, uint8_t* zero_mask, float* row_norms,
                                   void* stream) {
   if (!Ws || !dWs || rows < 0) return fail(OIVAE_E_ARG, "oivae_sgd_prox_f32: null pointer or negative rows");
-  if (H < 1 || H >= 512)
-    return fail(OIVAE_E_SHAPE, "oivae_sgd_prox_f32: H=%d outside [1,512)", H);
+  if (H < 1 || H > (1 << 20))
+    return fail(OIVAE_E_SHAPE, "oivae_sgd_prox_f32: H=%d outside [1, 2^20]", H);
   if (rows * 2 / 256 > 0x7fffffffLL) return fail(OIVAE_E_SHAPE, "oivae_sgd_prox_f32: too many rows");
   return launch_prox<true>(Ws, dWs, rows, H, lr, t, do_prox ? 1 : 0, zero_mask, row_norms, (hipStream_t)stream);
 }

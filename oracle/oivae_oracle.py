@@ -60,14 +60,16 @@ def row_sumsq_reference_order(w: np.ndarray) -> np.ndarray:
             P[0]+P[1]+P[2]+P[3] left to right; the scalar result starts at 0,
             takes the H%8 tail elements left to right and then lanes 0..7 of
             the combined vector left to right.
-  torch switches to a cascade once a partial sum takes 16 or more terms
-  (H >= 512); that regime is outside the hot path's shapes and is refused.
+  torch cascades once a partial sum takes 16 or more terms (H >= 512, aten
+  SumKernel multi_row_sum): every 16 steps of four vectors the four level-0
+  partial sums are added into level-1 ones and cleared, every 256 steps level 1
+  into level 2, every 4096 level 2 into level 3; the steps behind the last
+  full block of 16 go to level 0, then levels 1..3 are added to level 0 in
+  that order and the sum goes on as above.
   Every product and every sum is rounded to fp32 (no FMA).
   """
   w = np.asarray(w, dtype=np.float32)
   H = w.shape[-1]
-  if H >= 512:
-    raise ValueError("row_sumsq_reference_order: H >= 512 not pinned")
   sq = (w * w).astype(np.float32)
   lead = sq.shape[:-1]
   if H < 8:
@@ -85,9 +87,27 @@ def row_sumsq_reference_order(w: np.ndarray) -> np.ndarray:
   vec = sq[..., : V * 8].reshape(lead + (V, 8))
   P = [np.zeros(lead + (8,), np.float32) for _ in range(4)]
   nq = V // 4
-  for i in range(nq):
+  levels = [[np.zeros(lead + (8,), np.float32) for _ in range(4)] for _ in range(3)]   # levels 1..3
+  i = 0
+  while i + 16 <= nq:
+    for _ in range(16):
+      for k in range(4):
+        P[k] = (P[k] + vec[..., 4 * i + k, :]).astype(np.float32)
+      i += 1
+    below = P
+    for lev in range(3):
+      for k in range(4):
+        levels[lev][k] = (levels[lev][k] + below[k]).astype(np.float32)
+        below[k] = np.zeros(lead + (8,), np.float32)
+      if i & (15 << (4 * (lev + 1))):
+        break
+      below = levels[lev]
+  for i in range(i, nq):
     for k in range(4):
       P[k] = (P[k] + vec[..., 4 * i + k, :]).astype(np.float32)
+  for lev in range(3):
+    for k in range(4):
+      P[k] = (P[k] + levels[lev][k]).astype(np.float32)
   for i in range(nq * 4, V):
     P[0] = (P[0] + vec[..., i, :]).astype(np.float32)
   for k in range(1, 4):

@@ -73,8 +73,13 @@ void oivae_oracle_rsqrt14_array(const float* in, float* out, long n, const uint1
 }
 
 /* sum_h w[h]^2 in torch 2.10's CPU order for a contiguous fp32 inner dim
- * (aten SumKernel: vectorized_inner_sum / scalar_inner_sum, 8-lane vectors,
- * 4 interleaved accumulators).  H < 512 (no cascade step yet). */
+ * (aten SumKernel: vectorized_inner_sum -> row_sum -> multi_row_sum, 8-lane vectors,
+ * 4 interleaved vector accumulators = one "step" of 32 floats).  From 16 steps on
+ * (H >= 512) multi_row_sum cascades: every 16 steps the level-0 accumulators are added
+ * into level 1 and cleared, every 256 steps level 1 into level 2, every 4096 level 2
+ * into level 3 (level_power = max(4, ceil_log2(steps) / 4) = 4 below 2^20 steps);
+ * the steps left over after the last full block of 16 go to level 0, then levels
+ * 1..3 are added to level 0 in that order. */
 float oivae_oracle_row_sumsq(const float* w, int H) {
   if (H < 8) {
     float p[4] = {0, 0, 0, 0};
@@ -85,19 +90,33 @@ float oivae_oracle_row_sumsq(const float* w, int H) {
     for (int k = 1; k < 4; k++) p[0] = p[0] + p[k];
     return p[0];
   }
-  float P[4][8];
+  float P[4][4][8];   /* [level][accumulator][lane] */
   memset(P, 0, sizeof(P));
   int V = H / 8, nq = V / 4;
-  for (int i = 0; i < nq; i++)
+  int i = 0;
+  while (i + 16 <= nq) {
+    for (int j = 0; j < 16; j++, i++)
+      for (int k = 0; k < 4; k++)
+        for (int l = 0; l < 8; l++) { float a = w[(4 * i + k) * 8 + l]; P[0][k][l] = P[0][k][l] + a * a; }
+    for (int lev = 1; lev < 4; lev++) {
+      for (int k = 0; k < 4; k++)
+        for (int l = 0; l < 8; l++) { P[lev][k][l] = P[lev][k][l] + P[lev - 1][k][l]; P[lev - 1][k][l] = 0.0f; }
+      if ((i & (15 << (4 * lev))) != 0) break;
+    }
+  }
+  for (; i < nq; i++)
     for (int k = 0; k < 4; k++)
-      for (int l = 0; l < 8; l++) { float a = w[(4 * i + k) * 8 + l]; P[k][l] = P[k][l] + a * a; }
-  for (int i = nq * 4; i < V; i++)
-    for (int l = 0; l < 8; l++) { float a = w[i * 8 + l]; P[0][l] = P[0][l] + a * a; }
+      for (int l = 0; l < 8; l++) { float a = w[(4 * i + k) * 8 + l]; P[0][k][l] = P[0][k][l] + a * a; }
+  for (int lev = 1; lev < 4; lev++)
+    for (int k = 0; k < 4; k++)
+      for (int l = 0; l < 8; l++) P[0][k][l] = P[0][k][l] + P[lev][k][l];
+  for (int v = nq * 4; v < V; v++)
+    for (int l = 0; l < 8; l++) { float a = w[v * 8 + l]; P[0][0][l] = P[0][0][l] + a * a; }
   for (int k = 1; k < 4; k++)
-    for (int l = 0; l < 8; l++) P[0][l] = P[0][l] + P[k][l];
+    for (int l = 0; l < 8; l++) P[0][0][l] = P[0][0][l] + P[0][k][l];
   float acc = 0.0f;
-  for (int i = V * 8; i < H; i++) acc = acc + w[i] * w[i];
-  for (int l = 0; l < 8; l++) acc = acc + P[0][l];
+  for (int h = V * 8; h < H; h++) acc = acc + w[h] * w[h];
+  for (int l = 0; l < 8; l++) acc = acc + P[0][0][l];
   return acc;
 }
 
@@ -106,7 +125,7 @@ float oivae_oracle_row_sumsq(const float* w, int H) {
  * Returns 0, or 1 if H is outside the pinned range. */
 int oivae_oracle_prox_f32(float* Ws, long rows, int H, float t, const uint16_t* tab,
                           uint8_t* mask, float* norms_out) {
-  if (H < 1 || H >= 512) return 1;
+  if (H < 1 || H > (1 << 20)) return 1;
   for (long r = 0; r < rows; r++) {
     float* w = Ws + r * (long)H;
     float n = oivae_oracle_mkl_sqrtf(oivae_oracle_row_sumsq(w, H), tab);

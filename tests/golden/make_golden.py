@@ -226,6 +226,38 @@ def prox_vectors():
   print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def prox_vectors_wide():
+  """Rows of 512 floats and more, where ATen's row sum cascades (every 16 steps of 32 floats a level-0 flush, every
+  256 a level-1 flush, every 4096 a level-2 flush): widths on both sides of every boundary, rows at the threshold,
+  zero / tiny rows.  A file of its own (prox_vectors.npz stays as recorded)."""
+  rng = np.random.default_rng(4321)
+  out = {}
+  Hs = [512, 513, 520, 544, 1000, 1031, 4100, 8200, 131112]
+  out["Hs"] = np.array(Hs, np.int32)
+  for H in Hs:
+    big = H > 100000   # (one row, one threshold: the file stays small)
+    G, K = (1, 1) if big else (1, 5)
+    W = (rng.standard_normal((G, K, H)) * (0.2 + rng.random((G, K, 1)))).astype(np.float32)
+    t = np.float32(0.7 * math.sqrt(H))
+    if not big:
+      n = np.sqrt(np.sum(W[0, 0].astype(np.float64) ** 2))
+      W[0, 0] = (W[0, 0].astype(np.float64) * (float(t) / n)).astype(np.float32)
+      n = np.sqrt(np.sum(W[0, 1].astype(np.float64) ** 2))
+      W[0, 1] = (W[0, 1].astype(np.float64) * (float(np.nextafter(t, np.float32(1e9))) / n)).astype(np.float32)
+      W[0, 2] = 0
+      W[0, 3] = np.float32(1e-30)
+    out["H%d/W" % H] = W
+    out["H%d/t" % H] = np.float64(t)
+    out["H%d/out" % H] = reference_prox(W, float(0.5 * t if big else t))
+    if big:
+      out["H%d/t" % H] = np.float64(0.5 * t)
+    else:
+      out["H%d/out_small_t" % H] = reference_prox(W, 1e-4)
+  path = os.path.join(HERE, "prox_vectors_wide.npz")
+  np.savez_compressed(path, **out)
+  print("wrote", path, os.path.getsize(path), "bytes")
+
+
 MOCAP_DIMS = [3, 3, 3, 3, 3, 3, 3, 2, 3, 1, 1, 2, 1, 2, 2, 3, 1, 1, 2, 1, 2, 3, 1, 2, 1, 3, 1, 2, 1]
 
 
@@ -290,6 +322,8 @@ def main():
              lr=3e-3, Ws_lr=1e-6, lam=1, prior_rows="1", full_steps={0, 12, 29}, prepare=sparse_start)
   if not ONLY or "prox_vectors" in ONLY:
     prox_vectors()
+  if not ONLY or "prox_vectors_wide" in ONLY:
+    prox_vectors_wide()
 
 
 if __name__ == "__main__":

@@ -55,6 +55,37 @@ def test_prox_golden_vectors_bit_exact():
       assert np.array_equal(mask, np.all(want == 0, axis=-1).astype(np.uint8)), "H=%d %s mask" % (H, key)
 
 
+def test_wide_prox_golden_vectors_bit_exact():
+  """H >= 512 (prox_rows_wide: 32 lanes per row, one cascading accumulator chain each) against the vectors recorded
+  from the reference, and with the fused SGD update against the C oracle."""
+  from oracle import prox_oracle
+  z = np.load(os.path.join(GOLDEN, "prox_vectors_wide.npz"))
+  rng = np.random.default_rng(3)
+  for H in z["Hs"]:
+    W = z["H%d/W" % H]
+    keys = [("out", float(z["H%d/t" % H]))] + ([("out_small_t", 1e-4)] if "H%d/out_small_t" % H in z else [])
+    for key, t in keys:
+      got, mask, _ = _prox_gpu(W, t)
+      want = z["H%d/%s" % (H, key)]
+      assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "H=%d %s" % (H, key)
+      assert np.array_equal(mask, np.all(want == 0, axis=-1).astype(np.uint8)), "H=%d %s mask" % (H, key)
+    g = (rng.standard_normal(W.shape) * 20).astype(np.float32)
+    lr, t = 0.0078125, float(z["H%d/t" % H])
+    pre = (W.astype(np.float64) - lr * g.astype(np.float64)).astype(np.float32)
+    want, wmask, wnorms = prox_oracle.proximal_step(pre, t)
+    got, mask, norms = _prox_gpu(W, t, with_grad=g, lr=lr)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "H=%d sgd" % H
+    assert np.array_equal(mask, wmask) and np.array_equal(norms.view(np.uint32), wnorms.view(np.uint32))
+  # many rows of a wide H: every 32-lane group of the launch, partial last workgroup included
+  W = rng.standard_normal((37, 11, 1000)).astype(np.float32) * rng.random((37, 11, 1)).astype(np.float32)
+  t = float(np.median(np.sqrt((W.astype(np.float64) ** 2).sum(-1))))
+  want, wmask, wnorms = prox_oracle.proximal_step(W, t)
+  got, mask, norms = _prox_gpu(W, t)
+  assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+  assert np.array_equal(mask, wmask) and np.array_equal(norms.view(np.uint32), wnorms.view(np.uint32))
+  assert 0.3 < mask.mean() < 0.7
+
+
 def test_prox_random_vs_oracle_bit_exact():
   from oracle import prox_oracle
   rng = np.random.default_rng(7)

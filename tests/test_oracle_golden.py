@@ -21,12 +21,26 @@ def test_prox_vectors_bit_exact():
       assert np.array_equal(mask, np.all(want == 0, axis=-1).astype(np.uint8))
 
 
+def test_wide_prox_vectors_bit_exact():
+  """Rows of 512 floats and more (tests/golden/prox_vectors_wide.npz, recorded from the reference): ATen's row sum
+  cascades there -- a level flush every 16, 256 and 4096 steps of 32 floats -- and the oracle restates it."""
+  z = np.load(os.path.join(GOLDEN, "prox_vectors_wide.npz"))
+  for H in z["Hs"]:
+    W = z["H%d/W" % H]
+    keys = [("out", float(z["H%d/t" % H]))] + ([("out_small_t", 1e-4)] if "H%d/out_small_t" % H in z else [])
+    for key, t in keys:
+      got, mask = O.proximal_step_reference_order(W, t)
+      want = z["H%d/%s" % (H, key)]
+      assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "H=%d %s" % (H, key)
+      assert np.array_equal(mask, np.all(want == 0, axis=-1).astype(np.uint8))
+
+
 def test_row_sumsq_matches_torch_here():
   """Live check against torch's CPU kernel on this host (skipped silently on a
   host whose torch build orders the sum differently: the golden test above is
   the pin)."""
   rng = np.random.default_rng(0)
-  for H in list(range(1, 70)) + [96, 100, 128, 200, 256, 300, 511]:
+  for H in list(range(1, 70)) + [96, 100, 128, 200, 256, 300, 511, 512, 513, 543, 544, 1000, 4097, 8232, 131112]:
     a = rng.standard_normal((50, H)).astype(np.float32)
     want = torch.sum(torch.pow(torch.from_numpy(a).reshape(1, 50, H), 2), dim=2).numpy().reshape(-1)
     got = O.row_sumsq_reference_order(a)
