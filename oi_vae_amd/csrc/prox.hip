@@ -356,15 +356,24 @@ __global__ __launch_bounds__(256) void prox_rows_wide(float* __restrict__ Ws, co
 // consecutive k, so every row of a map is one coalesced access.  The sum order is torch 2.10's CPU
 // outer-reduction kernel, restated rule by rule in oracle/prox_oracle.c (multi_row_sumsq / row_sum_sumsq).
 __device__ __forceinline__ float cols_multi_row(const float* __restrict__ w, int64_t stride, int n) {
-  float a0 = 0.0f, a1 = 0.0f;
+  // aten multi_row_sum: level 0 flushed into level 1 every 16 rows, level 1 into level 2 every 256, level 2 into
+  // level 3 every 4096 (two levels are the same sum below 272 rows, where the first recorded vectors ended)
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
   int i = 0;
   while (i + 16 <= n) {
     for (int j = 0; j < 16; ++j, ++i) { const float v = w[(int64_t)i * stride]; a0 = a0 + v * v; }
     a1 = a1 + a0;
     a0 = 0.0f;
+    if ((i & (15 << 4)) == 0) {
+      a2 = a2 + a1;
+      a1 = 0.0f;
+      if ((i & (15 << 8)) == 0) { a3 = a3 + a2; a2 = 0.0f; }
+    }
   }
   for (; i < n; ++i) { const float v = w[(int64_t)i * stride]; a0 = a0 + v * v; }
   a0 = a0 + a1;
+  a0 = a0 + a2;
+  a0 = a0 + a3;
   return a0;
 }
 
@@ -507,9 +516,9 @@ extern "C" int oivae_sgd_prox_f32(float* Ws, const float* dWs, int64_t rows, int
 extern "C" int oivae_prox_cols_f32(float* W, const int32_t* group_off, int32_t G, int32_t K, int32_t max_group_rows,
                                    float t, uint8_t* zero_mask, float* col_norms, void* stream) {
   if (!W || !group_off || G < 0 || K < 1) return fail(OIVAE_E_ARG, "oivae_prox_cols_f32: null pointer or bad sizes");
-  if (max_group_rows < 1 || max_group_rows >= 512 || (int64_t)max_group_rows * K >= 32768)
+  if (max_group_rows < 1 || (int64_t)max_group_rows * K >= 32768 || (K == 1 && max_group_rows >= 512))
     return fail(OIVAE_E_SHAPE, "oivae_prox_cols_f32: H_g=%d, K=%d outside the range where the reference's column-sum "
-                               "order is pinned (H_g < 512, H_g*K < 32768)", max_group_rows, K);
+                               "order is pinned (H_g*K < 32768; K = 1: H_g < 512)", max_group_rows, K);
   const uint16_t* tab = rsqrt14_table_device();
   if (!tab) return fail(OIVAE_E_NOINIT, "oivae_init has not been called on this device");
   if (G == 0) return OIVAE_OK;

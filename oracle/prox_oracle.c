@@ -160,21 +160,28 @@ int oivae_oracle_prox_f32(float* Ws, long rows, int H, float t, const uint16_t* 
  *     (row r -> accumulator r mod 4, each a multi_row_sum over H/4 terms), leftover
  *     rows into accumulator 0, then accumulators 1..3 added in order;
  *   - K == 1 is a contiguous inner reduction: the order of oivae_oracle_row_sumsq.
- * Pinned for H_g < 512 and H_g*K < 32768 (single-threaded reduction, one cascade level).
+ * Pinned for H_g*K < 32768 (beyond it torch splits the columns over its threads, and which columns take which of
+ * the two paths above then depends on the host's thread count) and, for K == 1, H_g < 512.
  * ------------------------------------------------------------------------- */
 static float multi_row_sumsq(const float* w, long stride, int n) {
-  /* level step 16 for n < 2^20; with n < 512 at most two levels are ever non-zero */
-  float a0 = 0.0f, a1 = 0.0f;
+  /* aten multi_row_sum, level step 16 for n < 2^20: level 0 is flushed into level 1 every 16 terms, level 1 into
+   * level 2 every 256, level 2 into level 3 every 4096.  (Until round 2's last part this kept two levels only, which
+   * is the same sum below 272 terms -- the recorded vectors went to 255 -- and a different one from there on.) */
+  float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   int i = 0;
   while (i + 16 <= n) {
-    for (int j = 0; j < 16; j++, i++) { float v = w[(long)i * stride]; a0 = a0 + v * v; }
-    a1 = a1 + a0;
-    a0 = 0.0f;
+    for (int j = 0; j < 16; j++, i++) { float v = w[(long)i * stride]; a[0] = a[0] + v * v; }
+    for (int lev = 1; lev < 4; lev++) {
+      a[lev] = a[lev] + a[lev - 1];
+      a[lev - 1] = 0.0f;
+      if ((i & (15 << (4 * lev))) != 0) break;
+    }
   }
-  for (; i < n; i++) { float v = w[(long)i * stride]; a0 = a0 + v * v; }
-  a0 = a0 + a1;
-  a0 = a0 + 0.0f; /* levels 2 and 3 are zero; +0 keeps the bits (a0 is never -0: sums of squares) */
-  return a0;
+  for (; i < n; i++) { float v = w[(long)i * stride]; a[0] = a[0] + v * v; }
+  a[0] = a[0] + a[1];
+  a[0] = a[0] + a[2];
+  a[0] = a[0] + a[3];
+  return a[0];
 }
 
 static float row_sum_sumsq(const float* w, long stride, int n) {
@@ -202,7 +209,7 @@ int oivae_oracle_prox_cols_f32(float* W, const int32_t* group_off, int G, int K,
                                const uint16_t* tab, uint8_t* mask, float* norms_out) {
   for (int g = 0; g < G; g++) {
     int H = group_off[g + 1] - group_off[g];
-    if (H < 1 || H >= 512 || (long)H * K >= 32768) return 1;
+    if (H < 1 || (long)H * K >= 32768 || (K == 1 && H >= 512)) return 1;
   }
   for (int g = 0; g < G; g++) {
     float* Wg = W + (long)group_off[g] * K;

@@ -76,5 +76,43 @@ def main():
   print("wrote", len(names), "cases")
 
 
+def main_tall():
+  """Maps of 272 rows and more (fls_prox_vectors_tall.npz): from 272 rows on the column sum's cascade uses its third
+  level (a flush every 256 rows), from 4112 on its fourth; H_g * K stays under 32768, where torch reduces in one
+  thread."""
+  torch.manual_seed(0)
+  torch.set_num_threads(1)
+  rng = np.random.default_rng(5)
+  out = {}
+  names = []
+  cases = [(3, [272, 300]), (8, [511, 257]), (32, [600, 288]), (33, [300, 272, 400]), (40, [700]), (31, [1000]),
+           (7, [4097, 4112]), (2, [9000]), (5, [4200])]
+  for ci, (K, dims) in enumerate(cases):
+    W = [(rng.standard_normal((h, K)) * rng.uniform(0.05, 3.0)).astype(np.float32) for h in dims]
+    if K >= 3:
+      W[0][:, 0] = 0.0
+      W[-1][:, 1] = np.float32(1e-41)
+    norms = np.concatenate([np.sqrt((w.astype(np.float64) ** 2).sum(0)) for w in W])
+    t_med = np.float32(np.median(norms))
+    exact = torch.sqrt(torch.sum(torch.pow(torch.from_numpy(W[len(W) // 2]), 2), dim=0)).numpy()[K // 2]
+    for ti, t in enumerate((t_med, exact, np.nextafter(exact, np.float32(np.inf)))):
+      res, pen = run_case(dims, K, t, W)
+      name = "c%d_t%d" % (ci, ti)
+      names.append(name)
+      out[name + "/K"] = np.int32(K)
+      out[name + "/dims"] = np.asarray(dims, np.int32)
+      out[name + "/t"] = np.float32(t)
+      out[name + "/pen"] = np.float32(pen)
+      if ti == 0:
+        out["c%d/W" % ci] = np.concatenate(W, axis=0)
+      out[name + "/out"] = np.concatenate(res, axis=0)
+  out["names"] = np.asarray(names)
+  np.savez_compressed(os.path.join(HERE, "fls_prox_vectors_tall.npz"), **out)
+  print("wrote", len(names), "tall cases")
+
+
 if __name__ == "__main__":
-  main()
+  if "tall" in sys.argv[1:]:
+    main_tall()
+  else:
+    main()

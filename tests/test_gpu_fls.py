@@ -31,8 +31,9 @@ def _prox_cols_gpu(W, dims, t):
   return Wd.cpu().numpy(), mask.cpu().numpy(), norms.cpu().numpy()
 
 
-def test_column_prox_kernel_bit_exact_on_reference_vectors():
-  d = np.load(os.path.join(GOLDEN, "fls_prox_vectors.npz"))
+@pytest.mark.parametrize("fixture", ["fls_prox_vectors.npz", "fls_prox_vectors_tall.npz"])
+def test_column_prox_kernel_bit_exact_on_reference_vectors(fixture):
+  d = np.load(os.path.join(GOLDEN, fixture))
   for name in d["names"]:
     ci = name.split("_")[0]
     W, dims, t = d[ci + "/W"], d[name + "/dims"], float(d[name + "/t"])
@@ -47,11 +48,14 @@ def test_column_prox_kernel_bit_exact_on_reference_vectors():
 def test_column_prox_rejects_unpinned_shapes_and_empty_input():
   from oi_vae_amd import _lib
   L = _lib.init_device(0)
-  W = torch.zeros(600, 4, device="cuda")
+  W = torch.zeros(600, 64, device="cuda")
   off = torch.tensor([0, 600], dtype=torch.int32, device="cuda")
   st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-  assert L.oivae_prox_cols_f32(W.data_ptr(), off.data_ptr(), 1, 4, 600, 0.1, None, None, st) == 2  # OIVAE_E_SHAPE
+  # 600 x 64 = 38400 elements: torch would split the columns over its threads there (the result then depends on the
+  # host's thread count); a single column of 600 rows takes the inner-reduction order, pinned below 512 only
+  assert L.oivae_prox_cols_f32(W.data_ptr(), off.data_ptr(), 1, 64, 600, 0.1, None, None, st) == 2  # OIVAE_E_SHAPE
   assert b"pinned" in L.oivae_last_error()
+  assert L.oivae_prox_cols_f32(W.data_ptr(), off.data_ptr(), 1, 1, 600, 0.1, None, None, st) == 2
   assert L.oivae_prox_cols_f32(W.data_ptr(), off.data_ptr(), 0, 4, 1, 0.1, None, None, st) == 0     # no maps: no-op
   assert L.oivae_prox_cols_f32(None, off.data_ptr(), 1, 4, 1, 0.1, None, None, st) == 1            # OIVAE_E_ARG
 

@@ -106,12 +106,14 @@ def test_oracle_tracks_reference_through_a_sparse_trained_run():
   assert dead_seen >= 140 and z["step1/zero_mask"][3].all()      # the fixture is what it claims to be
 
 
-def test_column_prox_oracle_matches_reference_bits():
+@pytest.mark.parametrize("fixture,least", [("fls_prox_vectors.npz", 200), ("fls_prox_vectors_tall.npz", 27)])
+def test_column_prox_oracle_matches_reference_bits(fixture, least):
   """FirstLayerSparseDecoder.proximal_step (lib/models.py:65-71): the oracle's column-sum order, MKL root and
-  two-rounding scale against 228 cases recorded from the reference (tests/golden/make_golden_fls.py)."""
+  two-rounding scale against 228 cases recorded from the reference (tests/golden/make_golden_fls.py) and 27 more with
+  maps of 272 to 9000 rows, where the column sum's cascade uses its third and fourth level (`... tall`)."""
   from oracle import prox_oracle
-  d = np.load(os.path.join(GOLDEN, "fls_prox_vectors.npz"))
-  assert len(d["names"]) >= 200
+  d = np.load(os.path.join(GOLDEN, fixture))
+  assert len(d["names"]) >= least
   for name in d["names"]:
     ci = name.split("_")[0]
     W, dims, t = d[ci + "/W"], d[name + "/dims"], float(d[name + "/t"])
