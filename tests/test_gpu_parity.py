@@ -89,7 +89,8 @@ def test_wide_prox_golden_vectors_bit_exact():
 def test_prox_random_vs_oracle_bit_exact():
   from oracle import prox_oracle
   rng = np.random.default_rng(7)
-  for (G, K, H) in [(8192, 256, 8), (1024, 64, 64), (333, 7, 1), (40, 10, 5), (64, 33, 16), (17, 9, 100), (50, 20, 128)]:
+  for (G, K, H) in [(8192, 256, 8), (1024, 64, 64), (333, 7, 1), (40, 10, 5), (64, 33, 16), (17, 9, 100), (50, 20, 128),
+                    (13, 7, 300), (5, 9, 511), (6, 5, 519)]:
     W = rng.standard_normal((G, K, H)).astype(np.float32)
     t = float(np.median(np.sqrt((W.astype(np.float64) ** 2).sum(-1))))
     got, mask, norms = _prox_gpu(W, t)
