@@ -197,7 +197,7 @@ int oivae_encoder_bwd_f32(const oivae_shape_t* shape, const oivae_tensors_t* gra
  * of its kernels (dpre [B,2K], bias-gradient partials, the split image of dpre^T at the matrix-core shapes)
  * lives in a static device array of OIVAE_NOALLOC_SCRATCH_BYTES that each GPU holds from oivae_init until the
  * process ends.  Calls whose scratch would exceed it return OIVAE_E_WORKSPACE (need = 8*B*K bytes for dpre
- * + 16*K*min(256, ceil(B/64)) for the partials + 192*ceil(2K/128)*128*ceil(B/32) for the image when
+ * + 16*K*min(1024, ceil(B/16)) for the partials + 192*ceil(2K/128)*128*ceil(B/32) for the image when
  * 2K % 128 == 0, D % 128 == 0 and B % 32 == 0, else up to 16 partial images of 8*K*D bytes when the fp32
  * matrix-core kernel slices the batch; e.g. K=64: B <= 8192).  Calls no hipMalloc/hipFree or any
  * allocating routine; oivae_init(device) must have run.  Every call on a GPU shares that GPU's array: calls
