@@ -393,7 +393,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
           for (int fb = 0; fb < 4; ++fb)
-            xq[fb][nb] = *reinterpret_cast<const f32x4*>(xrow[nb] + (int64_t)(2 * pairIdx + q) * DG + 16 * fb);
+            xq[fb][nb] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xrow[nb] + (int64_t)(2 * pairIdx + q) * DG + 16 * fb));
         // ---- a1 + b1 in units of 1 / (s1 sz) ----
         f32x4 uT[4][2];
         init_t(uT, sb1);

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(768, 1) void enc_x3_gemm(const float* __restrict__ 
     auto xload = [&](int t, f32x4 (&r)[4]) {  // tiles past the end re-read the last one (never used)
       const int64_t k0 = xstep * (t < T ? t : T - 1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const f32x4*>(xptr[i] + k0);
+      for (int i = 0; i < 4; ++i) r[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xptr[i] + k0));
     };
     float xmax = 0.f;  // forward: max |x| seen by this lane, for the fp16 backward kernel's scale
     auto xstore = [&](int buf, const f32x4 (&r)[4]) {
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(768, 1) void enc_h2_bwd_gemm(const float* __restric
     auto xload = [&](int t, f32x4 (&r)[4]) {
       const int64_t k0 = xstep * (t < T ? t : T - 1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const f32x4*>(xptr[i] + k0);
+      for (int i = 0; i < 4; ++i) r[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xptr[i] + k0));
     };
     float xmax = 0.f;
     auto xstore = [&](int buf, const f32x4 (&r)[4]) {
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(768, 1) void enc_h2_fwd_gemm(const float* __restric
     auto xload = [&](int t, f32x4 (&r)[4]) {
       const int64_t k0 = 32 * (int64_t)(t < T ? t : T - 1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const f32x4*>(xptr[i] + k0);
+      for (int i = 0; i < 4; ++i) r[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xptr[i] + k0));
     };
     float xmax = 0.f;
     auto xstore = [&](int buf, const f32x4 (&r)[4]) {
