@@ -125,3 +125,35 @@ def test_column_prox_oracle_matches_reference_bits(fixture, least):
     assert np.array_equal(mask, wmask), name
     # group_lasso_penalty (lib/models.py:59-63) is the sum of the column norms the step used
     assert abs(float(norms.astype(np.float64).sum()) - float(d[name + "/pen"])) <= 2e-6 * max(1.0, abs(float(d[name + "/pen"])))
+
+
+def test_prox_oracles_match_torch_here_on_a_sweep_of_shapes():
+  """Live sweep against torch's CPU kernels on this host (the golden vectors are the pin; this is the net that
+  caught the column sum's missing cascade levels): the reference's two proximal steps written with the same torch
+  calls (lib/models.py:65-71, 106-111) against the C oracle, widths on every side of the 8 / 32 / 512 / 8192 boundaries
+  of the row sum and rows x columns on every side of the 4 / 8 / 32-column and 16 / 256 / 4096-row boundaries of the
+  column sum.  Skipped on a host whose torch orders these sums differently."""
+  from oracle import prox_oracle
+  torch.set_num_threads(1)
+  rng = np.random.default_rng(2)
+  for H in list(range(1, 70)) + list(range(70, 1100, 37)) + [511, 512, 513, 543, 544, 4095, 4096, 4104, 8191, 8192, 8224, 131104]:
+    W = (rng.standard_normal((2, 3, H)) * rng.uniform(0.1, 2.0)).astype(np.float32)
+    t = float(0.4 * np.sqrt(H))
+    Wt = torch.from_numpy(W.copy())
+    nn = torch.sqrt(torch.sum(torch.pow(Wt, 2), dim=2, keepdim=True))
+    Wt.div_(torch.clamp(nn, min=1e-16)); Wt.mul_(torch.clamp(nn - t, min=0))
+    got, _, _ = prox_oracle.proximal_step(W, t)
+    if not np.array_equal(got.view(np.uint32), Wt.numpy().view(np.uint32)):
+      pytest.skip("host torch differs from the oracle's row form at H=%d" % H)
+  for Hg in [1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 64, 100, 255, 256, 257, 271, 272, 273, 300, 511, 512, 1000, 4095, 4096, 4112, 4113]:
+    for K in [1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 40, 64, 65, 100]:
+      if Hg * K >= 32768 or (K == 1 and Hg >= 512):
+        continue
+      W = (rng.standard_normal((Hg, K)) * rng.uniform(0.1, 2.0)).astype(np.float32)
+      t = float(0.4 * np.sqrt(Hg))
+      Wt = torch.from_numpy(W.copy())
+      nn = torch.sqrt(torch.sum(torch.pow(Wt, 2), dim=0, keepdim=True))
+      Wt.div_(torch.clamp(nn, min=1e-16)); Wt.mul_(torch.clamp(nn - t, min=0))
+      got, _, _ = prox_oracle.proximal_step_cols(W, [Hg], t)
+      if not np.array_equal(got.view(np.uint32), Wt.numpy().view(np.uint32)):
+        pytest.skip("host torch differs from the oracle's column form at H_g=%d, K=%d" % (Hg, K))
