@@ -45,6 +45,24 @@ def test_column_prox_kernel_bit_exact_on_reference_vectors(fixture):
     assert np.array_equal(mask, wmask), name
 
 
+def test_column_prox_kernel_sweep_of_shapes_vs_oracle_bit_exact():
+  """Rows x columns on every side of the column sum's boundaries (4 / 8 / 32 columns; 16 / 256 / 4096 rows), two
+  ragged maps per launch, against the C oracle."""
+  from oracle import prox_oracle
+  rng = np.random.default_rng(12)
+  for Hg in [1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 64, 100, 255, 256, 257, 271, 272, 273, 300, 511, 512, 1000, 4096, 4113]:
+    for K in [1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 32, 33, 40, 64, 65, 100]:
+      if Hg * K >= 32768 or (K == 1 and Hg >= 512):
+        continue
+      dims = [Hg, max(1, Hg // 3)]
+      W = (rng.standard_normal((sum(dims), K)) * rng.uniform(0.1, 2.0)).astype(np.float32)
+      t = float(0.4 * np.sqrt(Hg))
+      want, wmask, wnorms = prox_oracle.proximal_step_cols(W, dims, t)
+      got, mask, norms = _prox_cols_gpu(W, dims, t)
+      assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (Hg, K)
+      assert np.array_equal(mask, wmask) and np.array_equal(norms.view(np.uint32), wnorms.view(np.uint32)), (Hg, K)
+
+
 def test_column_prox_rejects_unpinned_shapes_and_empty_input():
   from oi_vae_amd import _lib
   L = _lib.init_device(0)

@@ -86,6 +86,29 @@ def test_wide_prox_golden_vectors_bit_exact():
   assert 0.3 < mask.mean() < 0.7
 
 
+def test_prox_kernels_sweep_of_widths_vs_oracle_bit_exact():
+  """Every kernel path of the row form -- scalar (any H), two threads per row (H = 8, 16, 32, 64, 128), 32 threads per row
+  (H >= 512) -- on a sweep of widths against the C oracle, with and without the fused SGD update."""
+  from oracle import prox_oracle
+  rng = np.random.default_rng(11)
+  for H in list(range(1, 70)) + list(range(70, 1100, 41)) + [128, 256, 511, 512, 513, 543, 544, 2048, 4096, 4104, 8200]:
+    W = (rng.standard_normal((3, 5, H)) * rng.uniform(0.2, 2.0)).astype(np.float32)
+    W[1, 2] = 0
+    t = float(np.median(np.sqrt((W.astype(np.float64) ** 2).sum(-1))))
+    want, wmask, wnorms = prox_oracle.proximal_step(W, t)
+    got, mask, norms = _prox_gpu(W, t)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), H
+    assert np.array_equal(mask, wmask) and np.array_equal(norms.view(np.uint32), wnorms.view(np.uint32)), H
+    if H % 3 == 0:
+      g = (rng.standard_normal(W.shape) * 8).astype(np.float32)
+      lr = 0.03125
+      pre = (W.astype(np.float64) - lr * g.astype(np.float64)).astype(np.float32)
+      want, wmask, _ = prox_oracle.proximal_step(pre, t)
+      got, mask, _ = _prox_gpu(W, t, with_grad=g, lr=lr)
+      assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), ("sgd", H)
+      assert np.array_equal(mask, wmask), ("sgd", H)
+
+
 def test_prox_random_vs_oracle_bit_exact():
   from oracle import prox_oracle
   rng = np.random.default_rng(7)
