@@ -101,7 +101,8 @@ int64_t oivae_workspace_bytes(const oivae_shape_t* shape, int64_t B, int32_t S);
  * in place, for every row of Ws viewed as [rows, H]:
  *   n = sqrt(sum_h w^2); w = (w / max(n,1e-16)) * max(n - t, 0)
  * bit for bit as the reference's CPU path computes it (torch row-sum order,
- * MKL-VML square root, two roundings per element).  zero_mask[r] (optional)
+ * MKL-VML square root, two roundings per element; 1 <= H <= 2^20, the cascade
+ * of torch's row sum from H = 512 on included).  zero_mask[r] (optional)
  * = 1 iff the row is all zeros afterwards; row_norms (optional) = n. */
 int oivae_prox_f32(float* Ws, int64_t rows, int32_t H, float t,
                    uint8_t* zero_mask, float* row_norms, void* stream);
@@ -122,7 +123,9 @@ int oivae_sgd_prox_f32(float* Ws, const float* dWs, int64_t rows, int32_t H,
  * G+1 int32 prefix sums of H_g; max_group_rows the largest H_g.  In place, for every map g and
  * column k:  n = sqrt(sum_h W_g[h,k]^2); W_g[:,k] = (W_g[:,k] / max(n,1e-16)) * max(n - t, 0),
  * bit for bit as the reference's CPU path (torch's column-sum order over dim 0, MKL-VML root).
- * zero_mask / col_norms (optional): [G, K]. */
+ * Accepted: H_g * K < 32768 for every map (beyond it torch splits the columns over its threads and
+ * the reference's own result depends on the host's thread count) and, for K = 1, H_g < 512;
+ * else OIVAE_E_SHAPE.  zero_mask / col_norms (optional): [G, K]. */
 int oivae_prox_cols_f32(float* W, const int32_t* group_off, int32_t G, int32_t K, int32_t max_group_rows,
                         float t, uint8_t* zero_mask, float* col_norms, void* stream);
 
