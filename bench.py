@@ -191,34 +191,39 @@ def main():
   batches = [X, X2]
   egen = torch.Generator(device=device).manual_seed(7 + rank)
   t_prox = WS_LR * LAM
-  events = []
+  events = []   # (name, start, end) of the decoder entry point in the timed steps
+  diag = []     # ... of every entry point in the diagnostic steps
   sync = parallel.BucketedGradSync(eng) if world > 1 else None
   counter = [0]
   comm_marks = []
 
-  def step(timed, xs=None):
+  def step(timed, xs=None, diagnose=False):
+    """timed: the decoder entry point's events go to `events`; diagnose (the untimed steps behind the timed region):
+    every entry point's events go to `diag`, and the waits for the gradient buckets are bracketed too."""
     xs = batches if xs is None else xs
     Xs = xs[counter[0] % len(xs)]
     counter[0] += 1
     eps = torch.randn(1, rows, K, generator=egen, device=device)
-    if timed:
-      eng.trace = events
+    if diagnose:
+      eng.trace, eng.trace_names = diag, None
+    elif timed:
+      eng.trace, eng.trace_names = events, {"decoder"}
     eng.forward_backward(Xs, eps, 1.0, lam=LAM, grad_sync=sync)
-    eng.trace = None
+    eng.trace, eng.trace_names = None, None
     if sync is not None:
       # every bucket is averaged over ranks before ITS optimizers run: the decoder-side bucket (reduced under the
       # encoder backward GEMM) first, so that its Adam, SGD and prox run under the encoder bucket's all-reduce
-      # (timed steps: events on the compute stream around each wait = the time that stream stood still for a bucket,
-      # i.e. the communication the step did NOT hide)
-      marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
-      if timed: marks[0].record()
+      # (diagnostic steps: events on the compute stream around each wait = the time that stream stood still for a
+      # bucket, i.e. the communication the step did NOT hide)
+      marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if diagnose else None
+      if diagnose: marks[0].record()
       sync.wait_decoder()
-      if timed: marks[1].record()
+      if diagnose: marks[1].record()
       eng.adam_step(LR, part="dec")
       eng.sgd_prox_step(WS_LR, t_prox)
-      if timed: marks[2].record()
+      if diagnose: marks[2].record()
       sync.wait_encoder()
-      if timed:
+      if diagnose:
         marks[3].record()
         comm_marks.append(marks)
       eng.adam_step(LR, part="enc")
@@ -246,7 +251,14 @@ def main():
 
   for _ in range(args.warmup):
     step(False)
+  # Inside the timed region only the decoder entry point carries HIP events (the roofline needs its launch time): a
+  # pair of events per entry point costs ~0.05 ms per step (tools/trace_cost.py: 1.7 % of the step at an eighth of
+  # the batch).  The other entry points' times come from three more, untimed, steps behind it.
   dt = timed_steps(args.steps)
+  barrier()
+  for _ in range(3):
+    step(False, diagnose=True)
+  barrier()
 
   extras = {}
   if world == 1 and not args.no_extras:
@@ -288,7 +300,7 @@ def main():
     f16 = decoder_f16_flops(rows)
     tf = lambda fl: fl / sec / 1e12 if sec > 0 else 0.0
     per_kernel = {}
-    for name, a, b in events:
+    for name, a, b in diag:
       per_kernel.setdefault(name, []).append(a.elapsed_time(b))
     traffic = pmc_traffic() if world == 1 else None
     out = {
@@ -325,6 +337,8 @@ def main():
                            "wave's dependent sequence and the dz float atomics (8.6 GB per launch) bound it, DESIGN 3.0"},
       "step_model_tflops": (decoder_flops_per_row() + encoder_flops_per_row()) * GLOBAL_BATCH / (ms * 1e-3) / 1e12 / world,
       "entry_ms": {k: sum(v) / len(v) for k, v in per_kernel.items()},
+      "entry_ms_note": "three untimed steps behind the timed region, every entry point bracketed by HIP events; inside "
+                       "the timed region only the decoder's are recorded (roofline.avg_launch_ms)",
       "extra": extras,
       "arithmetic": "fp32 in, fp32 out, fp32 accumulation everywhere.  Encoder GEMMs and decoder products: two fp16 "
                     "terms per operand after an exact power-of-two scaling by the operand's maximum (or a bound of "

@@ -113,13 +113,14 @@ class Engine:
     self.adam_t = 0
     # optional per-entry-point timing: a list that receives (name, start_event, end_event)
     self.trace = None
+    self.trace_names = None   # with trace set: the entry points that get events (None = all of them)
     self.gen_sig_off = 1e-3
     self.bound = []  # (user tensor, grad view) pairs set by adopt()
     self._eval_grads = None
     self._eval_gt = None
 
   def _timed(self, name, fn):
-    if self.trace is None:
+    if self.trace is None or (self.trace_names is not None and name not in self.trace_names):
       return fn()
     a = torch.cuda.Event(enable_timing=True)
     b = torch.cuda.Event(enable_timing=True)
