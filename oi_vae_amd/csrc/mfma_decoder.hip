@@ -1840,8 +1840,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
         mA = fmaxf(mA, fabsf(A[o]));
         mW = fmaxf(mW, fabsf(tW2[o]));
       }
-      atomicMax(red + 0, __float_as_uint(mA));
-      atomicMax(red + 1, __float_as_uint(mW));
+      float gmx = 0.f;
       {   // eight lanes per output dimension d: sum_m |W2[d][m]|
         const int d = tid >> 3, part = tid & 7;
         float rs = 0.f;
@@ -1853,8 +1852,20 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
         if (part == 0) {
           const float gb = sC3[d] * (rs + fabsf(sb2[d]) + __uint_as_float(a.rng[0]));
           gbound[d] = gb;
-          atomicMax(red + 2, __float_as_uint(gb));
+          gmx = gb;
         }
+      }
+      // one LDS atomic per wave and maximum (see dec_x3_64s.h: 512 lanes on one LDS word cost 8 us per group)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        mA = fmaxf(mA, __shfl_xor(mA, o));
+        mW = fmaxf(mW, __shfl_xor(mW, o));
+        gmx = fmaxf(gmx, __shfl_xor(gmx, o));
+      }
+      if (lane == 0) {
+        atomicMax(red + 0, __float_as_uint(mA));
+        atomicMax(red + 1, __float_as_uint(mW));
+        atomicMax(red + 2, __float_as_uint(gmx));
       }
     }
     __syncthreads();
@@ -1872,7 +1883,9 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64g(MfmaDecArgs a) {
       float cs = 0.f;
 #pragma unroll
       for (int p8 = 0; p8 < 8; ++p8) cs += csp[p8 * 64 + tid];
-      atomicMax(red + 3, __float_as_uint(cs));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cs = fmaxf(cs, __shfl_xor(cs, o));
+      if (lane == 0) atomicMax(red + 3, __float_as_uint(cs));
     }
     __syncthreads();
     float q1, q2, qz, qg, qd, i1, i2, iz, ig, id;
