@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboivae_hip.so")
+# OIVAE_LIB_PATH: another build of the same library (A/B timing of a kernel change on one box; tools/ only)
+LIB_PATH = os.environ.get("OIVAE_LIB_PATH") or os.path.join(_HERE, "liboivae_hip.so")
 
 c_f = ctypes.c_float
 c_i32 = ctypes.c_int32

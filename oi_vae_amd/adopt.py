@@ -39,8 +39,21 @@ def _probe_affine_of_exp(mods):
   return c, off
 
 
-def probe_encoder_head(inference_net):
+def probe_encoder_head(inference_net, cache=None):
+  """(c, offset) of the encoder's sigma head exp(a)*c + offset, read by probing the modules behind its Linear in
+  float64 -- every step, because the scripts change c behind the model's back (a global captured by a lambda,
+  bars_data_oivae.py:60,85,258-259).  `cache` (a dict owned by the caller): one probe per step instead of three -- the
+  head is evaluated at 0 only, and while that value is the last step's, so are c and the offset."""
   mods = _as_list(inference_net.sigma_net)[1:]
+  if cache is not None:
+    x = torch.zeros(1, dtype=torch.float64)
+    for m in mods:
+      x = m(x)
+    f0 = float(x[0])
+    if cache.get("f0") == f0:
+      return cache["val"]
+    cache["f0"], cache["val"] = f0, _probe_affine_of_exp(mods)
+    return cache["val"]
   return _probe_affine_of_exp(mods)
 
 
@@ -124,8 +137,9 @@ def adopt(inference_net, generative_net, device=None) -> Engine:
     gv = eng.g[name] if g is None else eng.group_slices(name, g, grads=True)
     pv.copy_(t.detach().to(pv.device).reshape(pv.shape))
     t.data = pv.view(t.shape)
-    t.grad = None
-    pairs.append((t, gv.view(t.shape)))
+    gv = gv.view(t.shape)
+    t.grad = gv     # bound ONCE: the engine overwrites its flat gradient buffer completely on every step
+    pairs.append((t, gv))
 
   bind(lin_mu.weight, "enc_Wmu"); bind(lin_mu.bias, "enc_bmu")
   bind(lin_sig.weight, "enc_Wsig"); bind(lin_sig.bias, "enc_bsig")

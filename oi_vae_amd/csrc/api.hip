@@ -122,6 +122,10 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
   w->ranges = reinterpret_cast<uint32_t*>(take(256));
   w->enc_bwd_part = reinterpret_cast<float*>(take(enc_bwd_part_bytes(s, B, x3_encoder_bwd_applies(s, B))));
   w->x3_z = reinterpret_cast<uint32_t*>(take((plan.mfma && s.K == 64) ? ((N + 31) / 32) * 24 * 1024 : 0));
+  {
+    const int64_t a2 = plan.mfma ? mfma_decoder_acc2_bytes(s, N, plan.chunks) : 0;
+    w->dec_acc2 = a2 > 0 ? reinterpret_cast<float*>(take(a2)) : nullptr;
+  }
   w->total_bytes = off;
   if (p && bytes < off)
     return fail(OIVAE_E_WORKSPACE, "workspace too small: %lld < %lld bytes", (long long)bytes, (long long)off);

@@ -56,6 +56,7 @@ struct Workspace {
   uint32_t* x3_img;                        // x3 encoder: split image of the weights (fwd) / of dpre (bwd)
   uint32_t* ranges;                        // 64 words: operand maxima of the fp16 kernels (x3_encoder.hip "ranges")
   float*  enc_bwd_part;                    // fp32 matrix-core encoder backward: [slices][2K][D] partial images (few-tile shapes)
+  float*  dec_acc2;                        // dec_x3_64s: second-level slabs of its weight-gradient waves (nullptr: not needed)
   int64_t total_bytes;
 };
 
@@ -97,6 +98,7 @@ struct DecPlan {
 };
 
 DecPlan plan_decoder(const oivae_shape_t& s, int64_t N);
+int64_t mfma_decoder_acc2_bytes(const oivae_shape_t& s, int64_t N, int chunks);   // mfma_decoder.hip
 
 // flat (many-small-groups) decoder, flat_decoder.hip
 struct FlatLayout { int64_t oHc, oWc, oWk, oCt, oDzp, oImgA, oImgB, oImgC, total; int splits; bool h2; };

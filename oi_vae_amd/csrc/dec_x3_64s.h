@@ -52,6 +52,9 @@ __device__ __forceinline__ Frag2 split8_h2v(const f32x4& lo, const f32x4& hi) {
   return split8_h2(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
 }
 
+constexpr int kFlushRounds = 64;   // rounds (two tiles each per weight-gradient wave) between two moves to the second level (32: +0.13 ms at 65536 rows, dead groups 2.4e-6; 64: half of that, 5e-6)
+#define OIVAE_ACC2_ADD(p, v) (void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
 __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
   constexpr int K = 64, H = 64, M = 64, DG = 64, LW = 65;
   constexpr float kC = 2.885390081777927f;  // 2*log2(e): tanh(x) = 1 - 2/(exp2(kC x) + 1)
@@ -507,6 +510,39 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
     // producer j = 0: chain wave 2 wp + wgrp (this group is the first half of its row tile), j = 1: the other one
     uint32_t seen[2] = {0, 0};
     const int npub = 3 * ngrp;
+    // Second level of the two running sums.  The matrix instruction aligns its 32 products to the largest addend -- the
+    // accumulator -- and drops what falls below its window: once a running sum has grown over some hundred tiles, the
+    // lo x hi terms (2^-11 of the products) are partly lost, systematically when an operand hardly changes from row to
+    // row (a dead group: t = tanh(b1) on every row; dW2 off by 4e-5 of its scale at 65536 rows against float64,
+    // tools/probe/h2_accum_bias.hip, found by tests/test_gpu_fullsize.py).  So every kFlushRounds rounds (128 tiles) the
+    // wave moves its 128 accumulators into a slab of its own in the workspace -- a store the first time, float adds
+    // without return afterwards: no temporaries, nothing to wait for -- and starts them from zero; the slab comes back
+    // once, behind the row loop.  (Tried first: each tile's products into zeroed temporaries, added by vector
+    // instructions -- exact, but 77 spilled registers in this wave and 13.8 against 10.2 ms.)
+    // (uniform slab base in scalar registers + one 32-bit lane offset, made opaque at each use: formed ahead of the row
+    // loop, the 256 addresses would cost as many spilled registers)
+    char* const my2 = a.acc2 ? reinterpret_cast<char*>(a.acc2 + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + sw) * 8192) : nullptr;
+    bool flushed = false;
+    auto flush = [&]() {
+      uint32_t vo = (uint32_t)lane * 4u;
+      asm volatile("" : "+v"(vo));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* pw = reinterpret_cast<float*>(my2 + vo + ((i * 4 + j) * 4 + r) * 256);
+            float* pp = reinterpret_cast<float*>(my2 + 16384 + vo + ((i * 4 + j) * 4 + r) * 256);
+            if (!flushed) { *pw = dW2a[i][j][r]; *pp = Pa[i][j][r]; }
+            else { OIVAE_ACC2_ADD(pw, dW2a[i][j][r]); OIVAE_ACC2_ADD(pp, Pa[i][j][r]); }
+          }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dW2a[i][j] = (f32x4)(0.f); Pa[i][j] = (f32x4)(0.f); }
+      flushed = true;
+    };
     const int sr = lq & 1;   // rows 8 q + e: their 16-column blocks are swapped for odd q
     for (int rnd = 0; rnd < nrounds; ++rnd) {
 #pragma unroll
@@ -568,6 +604,23 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
           h2mm16<4>(Pa[mb], d, zn);
         }
       }
+      if (my2 != nullptr && (rnd + 1) % kFlushRounds == 0 && rnd + 1 < nrounds) flush();
+    }
+    if (flushed) {   // the slab back on top of the last rounds' sums (this wave's own adds: complete once vmcnt drains)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      uint32_t vo = (uint32_t)lane * 4u;
+      asm volatile("" : "+v"(vo));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float* pw = reinterpret_cast<const float*>(my2 + vo + ((i * 4 + j) * 4 + r) * 256);
+            const float* pp = reinterpret_cast<const float*>(my2 + 16384 + vo + ((i * 4 + j) * 4 + r) * 256);
+            dW2a[i][j][r] += __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            Pa[i][j][r] += __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
     }
     {   // the accumulated weight gradients back into true units
       const float kW = wgrp ? invW[1] : invW[0], kP = wgrp ? invP[1] : invP[0];

@@ -59,6 +59,7 @@ struct MfmaDecArgs {
   const uint32_t* gate;  // gated launch: returns at once when *gate == 0 (nullptr: always runs)
   uint32_t* err;         // the library's error word (host-mapped), raised by a timed-out LDS wait
   int G;
+  float* acc2;           // dec_x3_64s: second-level slabs of the weight-gradient waves (nullptr: short launches, no second level)
 };
 
 __device__ __forceinline__ float fast_tanh(float x) {
@@ -2514,6 +2515,16 @@ static int launch_one(const MfmaDecArgs& a, int G, int chunks, hipStream_t st) {
   return OIVAE_OK;
 }
 
+// dec_x3_64s: bytes of second-level slabs (one of 128 x 64 floats per weight-gradient wave) -- 0 when a launch has no
+// more rounds than one flush interval, or when another kernel runs
+int64_t mfma_decoder_acc2_bytes(const oivae_shape_t& s, int64_t N, int chunks) {
+  if (!dec_all64(s)) return 0;
+  const int64_t ntiles = (N + 31) / 32;
+  const int64_t nrounds = (ntiles + 4 * (int64_t)chunks - 1) / (4 * (int64_t)chunks);
+  if (nrounds <= kFlushRounds) return 0;
+  return (int64_t)((s.G + 1) / 2) * chunks * 4 * 8192 * (int64_t)sizeof(float);
+}
+
 int mfma_decoder_chunks(const oivae_shape_t& s, int64_t N) {
   const int64_t wave_tiles = (N + 31) / 32;
   int64_t c = (1024 + s.G - 1) / s.G;               // aim for >= 1024 workgroups
@@ -2550,6 +2561,7 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   a.ll_part = w.ll_part;
   a.zimg = nullptr;
   a.rng = nullptr;
+  a.acc2 = nullptr;
   int rc;
   const char* dec_env = test_hooks().dec[0] ? test_hooks().dec : nullptr;
   // test hooks: OIVAE_DEC=v1 the layer-by-layer fp32 template kernel (which also serves launches whose dz image
@@ -2597,6 +2609,7 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
       const dim3 grid((unsigned)((s.G + 1) / 2), (unsigned)chunks);
       a.rng_seen = rng + 6;
+      a.acc2 = use_s ? w.dec_acc2 : nullptr;
       hipLaunchKernelGGL(kern, grid, dim3(512), (size_t)kPairLds, st, a);
       OIVAE_LAUNCH_CHECK();
       launch_range_guard(rng, 6, 7, st);

@@ -156,19 +156,34 @@ class Engine:
 
   def load_params(self, params: Dict[str, object]):
     """params in the oracle's layout (lists per group for generator tensors)."""
+    self._import(self.p, params, with_Ws=True)
+
+  def _import(self, dst, params, with_Ws):
     s = self.spec
 
-    def put(dst, arr):
+    def put(d, arr):
       t = torch.as_tensor(np.asarray(arr, np.float32)) if not torch.is_tensor(arr) else arr.detach().float()
-      dst.copy_(t.reshape(dst.shape))
+      d.copy_(t.reshape(d.shape))
 
-    for n in ("enc_Wmu", "enc_bmu", "enc_Wsig", "enc_bsig", "Ws"):
-      put(self.p[n], params[n])
+    for n in ("enc_Wmu", "enc_bmu", "enc_Wsig", "enc_bsig") + (("Ws",) if with_Ws else ()):
+      put(dst[n], params[n])
     for n in ("gen_W2", "gen_b2", "log_sigma"):
-      put(self.p[n], np.concatenate([np.asarray(a, np.float32) for a in params[n]], axis=0))
+      put(dst[n], np.concatenate([np.asarray(a, np.float32) for a in params[n]], axis=0))
     if s.gen_type == "mlp":
-      put(self.p["gen_W1"], np.stack([np.asarray(a, np.float32) for a in params["gen_W1"]]))
-      put(self.p["gen_b1"], np.stack([np.asarray(a, np.float32) for a in params["gen_b1"]]))
+      put(dst["gen_W1"], np.stack([np.asarray(a, np.float32) for a in params["gen_W1"]]))
+      put(dst["gen_b1"], np.stack([np.asarray(a, np.float32) for a in params["gen_b1"]]))
+
+  def load_adam_state(self, exp_avg: Dict[str, object], exp_avg_sq: Dict[str, object], steps_done: int):
+    """The fused Adam's moments and step count from torch.optim.Adam's per-parameter state (the oracle's layout):
+    resumes a run -- or runs one step teacher-forced -- from a state recorded elsewhere."""
+    n = self.adam_numel
+    self.adam_m = torch.zeros(n, dtype=torch.float32, device=self.device)
+    self.adam_v = torch.zeros(n, dtype=torch.float32, device=self.device)
+    shapes = self.spec.seg_shapes()
+    for flat, src in ((self.adam_m, exp_avg), (self.adam_v, exp_avg_sq)):
+      views = {k: self._view(flat, k, shapes[k]) for k in _SEG_ORDER if k != "Ws"}
+      self._import(views, src, with_Ws=False)
+    self.adam_t = int(steps_done)
 
   def _export(self, src) -> Dict[str, object]:
     s = self.spec

@@ -36,6 +36,10 @@ class _EngineOptimizer(object):
     return vals.pop()
 
   def zero_grad(self, set_to_none=True):
+    """Attached to an engine: nothing to do -- every parameter's .grad is a view of the engine's flat gradient buffer,
+    bound once, and each step overwrites that buffer completely (no loop over thousands of per-group tensors)."""
+    if self._engine is not None:
+      return
     for g in self.param_groups:
       for p in g["params"]:
         p.grad = None

@@ -319,6 +319,22 @@ class OracleTrainer:
     self.adam = torch.optim.Adam(self.model.adam_params(), lr=lr)
     self.sgd = torch.optim.SGD([self.model.Ws], lr=Ws_lr, momentum=0)
 
+  def load_adam_state(self, exp_avg, exp_avg_sq, steps_done):
+    """Adam's moments and step count from a recorded state (dicts in `OracleModel.export`'s layout): the next
+    `step` then continues that run (teacher-forced parity checks)."""
+    m = self.model
+    def items(d):
+      out = [d["enc_Wmu"], d["enc_bmu"], d["enc_Wsig"], d["enc_bsig"]]
+      for g in range(m.G):
+        if m.typ == "mlp":
+          out += [d["gen_W1"][g], d["gen_b1"][g]]
+        out += [d["gen_W2"][g], d["gen_b2"][g]]
+      return out + list(d["log_sigma"])
+    for p, a, b in zip(m.adam_params(), items(exp_avg), items(exp_avg_sq)):
+      self.adam.state[p] = {"step": torch.tensor(float(steps_done)),
+                            "exp_avg": torch.tensor(np.asarray(a, np.float32)).reshape(p.shape).clone(),
+                            "exp_avg_sq": torch.tensor(np.asarray(b, np.float32)).reshape(p.shape).clone()}
+
   def step(self, X, eps, c, prox_step_size, want_grads=True, want_pre_prox=False):
     """One training step, lib/oivae.py:42-90.  Returns python scalars of the
     six reported terms (pre-update values), optionally the gradients, and the

@@ -18,10 +18,10 @@ def load(name):
   return z, spec
 
 
-def params_at(z, spec, prefix):
-  """prefix: 'init/' or 'stepN/post/' or 'stepN/grad/'."""
+def params_at(z, spec, prefix, with_Ws=True):
+  """prefix: 'init/' or 'stepN/post/' or 'stepN/grad/'; 'stepN/adam_m/' / 'stepN/adam_v/' (Adam's moments: no Ws)."""
   G = len(spec["group_dims"])
-  p = {k: z[prefix + k] for k in ("enc_Wmu", "enc_bmu", "enc_Wsig", "enc_bsig", "Ws")}
+  p = {k: z[prefix + k] for k in ("enc_Wmu", "enc_bmu", "enc_Wsig", "enc_bsig") + (("Ws",) if with_Ws else ())}
   p["gen_W2"] = [z[prefix + "gen_W2/%d" % g] for g in range(G)]
   p["gen_b2"] = [z[prefix + "gen_b2/%d" % g] for g in range(G)]
   p["log_sigma"] = [z[prefix + "log_sigma/%d" % g] for g in range(G)]
@@ -47,3 +47,18 @@ def rel_err(a, b):
   b = np.asarray(b, np.float64)
   scale = max(float(np.max(np.abs(b))) if b.size else 0.0, 1e-30)
   return float(np.max(np.abs(a - b))) / scale if b.size else 0.0
+
+
+def elementwise_within(a, b, rel=1e-5, floor=1e-3):
+  """(fraction, count): of the elements of the reference tensor b whose magnitude is at least `floor` of the tensor's
+  largest, the fraction at which a is within `rel` of THE ELEMENT ITSELF (not of the tensor's scale, as rel_err)."""
+  a = np.asarray(a, np.float64).ravel()
+  b = np.asarray(b, np.float64).ravel()
+  if b.size == 0:
+    return 1.0, 0
+  big = np.abs(b) >= floor * np.max(np.abs(b))
+  n = int(big.sum())
+  if n == 0:
+    return 1.0, 0
+  ok = np.abs(a[big] - b[big]) <= rel * np.abs(b[big])
+  return float(ok.mean()), n

@@ -112,10 +112,32 @@ def export_params(inference_net, gen, typ, grads=False):
 ONLY = set(sys.argv[1:])   # config names to (re)generate; none given = all
 
 
+def adam_state(adam, inference_net, gen, typ, key):
+  """torch.optim.Adam's per-parameter state (`exp_avg` / `exp_avg_sq`) in the layout of export_params."""
+  def val(p):
+    return adam.state[p][key].detach().numpy().copy()
+  out = {}
+  out["enc_Wmu"] = val(inference_net.mu_net[0].weight)
+  out["enc_bmu"] = val(inference_net.mu_net[0].bias)
+  out["enc_Wsig"] = val(inference_net.sigma_net[0].weight)
+  out["enc_bsig"] = val(inference_net.sigma_net[0].bias)
+  for g, gg in enumerate(gen.group_generators):
+    lin2 = gg.mu_net if typ == "linear" else gg.mu_net[1] if typ == "tanh_linear" else gg.mu_net[2]
+    if typ == "mlp":
+      out["gen_W1/%d" % g] = val(gg.mu_net[0].weight)
+      out["gen_b1/%d" % g] = val(gg.mu_net[0].bias)
+    out["gen_W2/%d" % g] = val(lin2.weight)
+    out["gen_b2/%d" % g] = val(lin2.bias)
+    out["log_sigma/%d" % g] = val(gg.sigma_net.extra_args[0])
+  return out
+
+
 def run_config(name, spec, seed, steps, lr, Ws_lr, lam, prior_rows, sigma_theta=1.0, data="uniform",
-               full_steps=None, prepare=None):
+               full_steps=None, prepare=None, state_steps=()):
   """steps: list of dicts(B=, S=, c=, t=).  full_steps: step indices whose gradients, post-step parameters and
   pre-prox Ws are recorded (None: every step); scalars, inputs and the zero mask are recorded for every step.
+  state_steps: step indices after which Adam's moments are recorded too (stepN/adam_m/..., stepN/adam_v/...), so
+  that step N+1 can be run TEACHER-FORCED from the reference's own complete state.
   prepare(inference_net, gen): harness-side preparation of the initial state (the state is the caller's)."""
   if ONLY and name not in ONLY:
     return
@@ -171,6 +193,10 @@ def run_config(name, spec, seed, steps, lr, Ws_lr, lam, prior_rows, sigma_theta=
       for k, v in export_params(inference_net, gen, typ).items():
         out[pre + "post/" + k] = v
       out[pre + "pre_prox_Ws"] = gen.pre_prox.numpy().copy()
+    if i in state_steps:
+      for key, tag in (("exp_avg", "adam_m/"), ("exp_avg_sq", "adam_v/")):
+        for k, v in adam_state(adam, inference_net, gen, typ, key).items():
+          out[pre + tag + k] = v
     out[pre + "zero_mask"] = (gen.Ws.data.abs().sum(dim=2) == 0).numpy().astype(np.uint8)
     print(name, "step", i, "elbo", float(info["elbo"]), "zero rows", int(out[pre + "zero_mask"].sum()),
           "of", out[pre + "zero_mask"].size)
@@ -319,7 +345,8 @@ def main():
              dict(D=320, K=64, H=64, M=64, gen_type="mlp", group_dims=[64] * 5), seed=21,
              steps=[dict(B=64, S=1, c=0.1, t=0.28)] * 10 + [dict(B=64, S=1, c=1.0, t=0.28)] * 16 +
                    [dict(B=45, S=2, c=1.0, t=0.05)] * 4,
-             lr=3e-3, Ws_lr=1e-6, lam=1, prior_rows="1", full_steps={0, 12, 29}, prepare=sparse_start)
+             lr=3e-3, Ws_lr=1e-6, lam=1, prior_rows="1", full_steps={0, 11, 12, 28, 29}, prepare=sparse_start,
+             state_steps={11, 28})
   if not ONLY or "prox_vectors" in ONLY:
     prox_vectors()
   if not ONLY or "prox_vectors_wide" in ONLY:

@@ -1,0 +1,136 @@
+"""The HIP path at BASELINE.json's FULL sizes against an independent reference -- not against itself:
+
+  * scale-up (configs[3]: G = 1024 x 64, K = H = M = 64, B = 65536): every scalar and every gradient against a float64
+    torch statement of the step on the same GPU (tests/_f64_reference.py, pinned on the CPU by the reference-recorded
+    fixtures: tests/test_f64_reference.py) -- on the initial state and on a sparse "trained" one;
+  * wide-prox (configs[4]: G = 8192 x 4, K = 256, H = 8, B = 1024): the same;
+  * MEG at its real size (configs[2]: 44 ragged sensor regions, D = 8184, K = 10, H = 1, B = 4096): one whole step
+    (gradients, Adam, SGD, proximal step) against the live CPU oracle.
+
+Tolerances are the north star's: scalars 1e-5 relative, gradients 2e-5 and post-step weights 1e-5 of the tensor's
+scale -- per REFERENCE tensor, i.e. per group for the generator tensors (the reference keeps one tensor per group)."""
+import numpy as np
+import pytest
+import torch
+
+from tests._f64_reference import f64_step
+from tests._fixtures import flat_items, rel_err
+
+pytestmark = pytest.mark.gpu
+SCALARS = ("z_kl", "loglik_term", "logprob_theta", "logprob_W", "loss", "elbo")
+
+
+def _check_against_f64(eng, X, eps, c, out, tag, rows_per_chunk, gtol=2e-5):
+  sc, ref = f64_step(eng, X, eps, c, rows_per_chunk=rows_per_chunk)
+  got = out["scalars"].double().cpu().numpy()
+  for j, k in enumerate(SCALARS):
+    assert abs(got[j] - sc[k]) <= 1e-5 * max(abs(sc[k]), 1.0), (tag, k, got[j], sc[k])
+  s = eng.spec
+  worst = {}
+  for name, r in ref.items():
+    g = eng.g[name].double()
+    assert torch.isfinite(g).all(), (tag, name)
+    # per reference tensor: the encoder's four and Ws whole, the generator tensors group by group
+    if name in ("gen_W1", "gen_b1"):
+      d, sc_ = (g - r).abs().flatten(1).amax(1), r.abs().flatten(1).amax(1)
+    elif name in ("gen_W2", "gen_b2", "log_sigma") and len(set(s.group_dims)) == 1:
+      d, sc_ = (g - r).abs().reshape(s.G, -1).amax(1), r.abs().reshape(s.G, -1).amax(1)
+    elif name in ("gen_W2", "gen_b2", "log_sigma"):
+      o = [int(x) for x in eng.group_off_host]
+      d = torch.stack([(g[o[i]:o[i + 1]] - r[o[i]:o[i + 1]]).abs().max() for i in range(s.G)])
+      sc_ = torch.stack([r[o[i]:o[i + 1]].abs().max() for i in range(s.G)])
+    else:
+      d, sc_ = (g - r).abs().max().view(1), r.abs().max().view(1)
+    # a reference tensor that is identically zero (a dead group's weight gradient) must be zero here too
+    err = float(torch.where(sc_ > 0, d / sc_.clamp(min=1e-300), (d > 0).double() * 1e9).max())
+    worst[name] = err
+    assert err < gtol, (tag, name, err)
+  return worst
+
+
+def _scaleup_engine(seed):
+  from tests.test_gpu_scale import _engine
+  return _engine(1024, 64, 64, 64, 64, seed=seed)
+
+
+def test_scaleup_full_size_against_float64_reference():
+  """G = 1024, B = 65536 (the bench's launch: dec_x3_64s with 512 workgroups, the h2 encoder kernels at full width)
+  against float64: on a fresh model, and after the state was driven sparse -- a third of Ws's rows exactly zero, eight
+  groups dead, log_sigma spread over a decade and a half, the generators' weights scaled group by group."""
+  B, K = 65536, 64
+  eng = _scaleup_engine(seed=3)
+  g = torch.Generator(device="cuda").manual_seed(17)
+  X = torch.rand(B, 1024 * 64, generator=g, device="cuda")
+  eps = torch.randn(1, B, K, generator=g, device="cuda")
+  out = eng.forward_backward(X, eps, 1.0)
+  torch.cuda.synchronize()
+  w0 = _check_against_f64(eng, X, eps, 1.0, out, "fresh", rows_per_chunk=2048)
+  # sparse, spread state
+  dead_rows = torch.rand(1024, 64, generator=g, device="cuda") < 0.33
+  eng.p["Ws"][dead_rows] = 0.0
+  eng.p["Ws"][100:108] = 0.0
+  eng.p["log_sigma"].copy_(torch.log(10 ** (torch.rand(1024 * 64, generator=g, device="cuda") * 1.5 - 2.5)))
+  eng.p["gen_W2"].mul_((0.3 + 2.0 * torch.rand(1024, 1, 1, generator=g, device="cuda")).expand(1024, 64, 1).reshape(-1, 1))
+  eng.p["gen_W1"].mul_(0.3 + 2.0 * torch.rand(1024, 1, 1, generator=g, device="cuda"))
+  out = eng.forward_backward(X, eps, 0.6)
+  torch.cuda.synchronize()
+  w1 = _check_against_f64(eng, X, eps, 0.6, out, "sparse", rows_per_chunk=2048)
+  print("\nfull scale-up vs float64, worst error / scale per reference tensor: fresh %s | sparse %s"
+        % ({k: "%.1e" % v for k, v in w0.items()}, {k: "%.1e" % v for k, v in w1.items()}))
+
+
+def test_wide_prox_full_size_against_float64_reference():
+  from oi_vae_amd import Engine, ModelSpec
+  G, dg, K, H, B = 8192, 4, 256, 8, 1024
+  eng = Engine(ModelSpec(D=G * dg, K=K, H=H, M=0, group_dims=[dg] * G, gen_type="linear"), device="cuda:0")
+  g = torch.Generator(device="cuda").manual_seed(21)
+  for n in ("enc_Wmu", "enc_bmu", "enc_Wsig", "enc_bsig", "gen_W2", "gen_b2"):
+    scale = 0.25 if n.startswith("gen") else 0.003
+    eng.p[n].copy_((torch.rand(eng.p[n].shape, generator=g, device="cuda") * 2 - 1) * scale)
+  eng.p["log_sigma"].fill_(float(np.log(1e-2)))
+  eng.p["Ws"].copy_(torch.randn(eng.p["Ws"].shape, generator=g, device="cuda"))
+  eng.p["Ws"][torch.rand(G, K, generator=g, device="cuda") < 0.5] = 0.0     # the state this config lives in
+  X = torch.rand(B, G * dg, generator=g, device="cuda")
+  eps = torch.randn(1, B, K, generator=g, device="cuda")
+  out = eng.forward_backward(X, eps, 1.0)
+  torch.cuda.synchronize()
+  w = _check_against_f64(eng, X, eps, 1.0, out, "wide", rows_per_chunk=256)
+  print("\nfull wide-prox vs float64: %s" % {k: "%.1e" % v for k, v in w.items()})
+
+
+def test_meg_real_size_whole_step_against_cpu_oracle():
+  """meg_oi_vae.py's shape at the size the survey gives it (44 labels, ~186 vertices each, K = 10, H = 1, batch 4096,
+  Ws_lr = 1e-6; a threshold that kills rows): gradients, Adam, SGD and the proximal step against the oracle run live on the host."""
+  from oi_vae_amd import Engine, ModelSpec
+  from oracle import oivae_oracle as O
+  rng = np.random.default_rng(44)
+  dims = rng.integers(120, 253, 44)
+  dims = (dims + (8184 - int(dims.sum())) // 44).tolist()     # ragged label sizes around 186 vertices ...
+  dims[-1] += 8184 - sum(dims)                                # ... that sum to D
+  assert min(dims) > 50 and sum(dims) == 8184
+  spec = dict(D=8184, K=10, H=1, M=0, gen_type="linear", group_dims=dims)
+  params = O.init_params(spec, seed=3)
+  B = 4096
+  X = rng.standard_normal((B, 8184)).astype(np.float32)
+  eps = rng.standard_normal((1, B, 10)).astype(np.float32)
+  torch.set_num_threads(16)
+  tr = O.OracleTrainer(spec, params, lr=1e-3, Ws_lr=1e-6, lam=1.0)
+  info = tr.step(X, eps, c=0.1, prox_step_size=0.5)   # H = 1, Ws ~ N(0, 1): the threshold kills about four rows in ten
+  eng = Engine(ModelSpec(D=8184, K=10, H=1, group_dims=dims, gen_type="linear"), device="cuda:0")
+  eng.load_params(params)
+  out = eng.forward_backward(X, eps, 0.1)
+  torch.cuda.synchronize()
+  sc = out["scalars"].cpu().numpy()
+  for j, k in enumerate(SCALARS):
+    assert abs(sc[j] - info[k]) <= 1e-5 * max(abs(info[k]), 1.0), (k, sc[j], info[k])
+  got_g = dict(flat_items(eng.export_grads()))
+  for k, b in flat_items(info["grads"]):
+    assert rel_err(got_g[k], b) < 2e-5, ("grad", k, rel_err(got_g[k], b))
+  eng.adam_step(1e-3)
+  eng.sgd_prox_step(1e-6, 0.5)
+  torch.cuda.synchronize()
+  got_p = dict(flat_items(eng.export_params()))
+  for k, b in flat_items(tr.model.export()):
+    assert rel_err(got_p[k], b) < 1e-5, ("param", k, rel_err(got_p[k], b))
+  assert np.array_equal(eng.zero_mask.cpu().numpy(), info["zero_mask"])
+  assert 100 < int(info["zero_mask"].sum()) < 340

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests._fixtures import GOLDEN, STEP_CONFIGS, flat_items, load, params_at, rel_err
+from tests._fixtures import GOLDEN, STEP_CONFIGS, elementwise_within, flat_items, load, params_at, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -181,9 +181,9 @@ def test_sparse_trained_run_matches_reference_golden():
   initial values by lr = 2e-2, the std head switched 0.1 -> 1 at step 10, a ragged S = 2 batch at the end.
   Scalars 1e-5 relative and the zero set exact at EVERY step, free-running; the teacher-forced proximal step bit-exact
   and gradients / post-step parameters at the steps the fixture holds them for: step 0 at the usual 2e-5 / 1e-5 of
-  scale, steps 12 and 29 at 5e-5 / 3e-5 -- by then the two runs are on their own trajectories and Adam's
-  element-wise normalisation has carried 1e-6 gradient differences into the weights for that many steps (measured:
-  2.4e-5 / 1.4e-5 at step 29)."""
+  scale, steps 11, 12, 28 and 29 at 5e-5 / 3e-5 -- by then the two runs are on their own trajectories.  The PER-STEP bar
+  at those steps (2e-5 / 1e-5 from the reference's own state) is test_teacher_forced_steps_of_the_trained_run below,
+  and whose drift this is -- the kernels' or any fp32 trajectory's -- is test_free_running_drift_... ."""
   z, spec = load("c4_trained64")
   eng = _engine(spec)
   eng.load_params(params_at(z, spec, "init/"))
@@ -199,7 +199,7 @@ def test_sparse_trained_run_matches_reference_golden():
       want = float(z[pre + k])
       assert abs(sc[j] - want) <= 1e-5 * max(abs(want), 1.0), (i, k, sc[j], want)
     full = (pre + "post/Ws") in z.files
-    gtol, ptol = (2e-5, 1e-5) if i == 0 else (5e-5, 3e-5)
+    gtol, ptol = (2e-5, 1e-5) if i == 0 else (5e-5, 3e-5)   # free-running; the per-step bar is the teacher-forced test
     if full:
       got_g = dict(flat_items(eng.export_grads()))
       for k, b in flat_items(params_at(z, spec, pre + "grad/")):
@@ -215,3 +215,122 @@ def test_sparse_trained_run_matches_reference_golden():
       got, mask, _ = _prox_gpu(z[pre + "pre_prox_Ws"], t)
       assert np.array_equal(got.view(np.uint32), z[pre + "post/Ws"].view(np.uint32)), i
       assert np.array_equal(mask, z[pre + "zero_mask"])
+
+
+def _trained_run(hooks=None, upto=30):
+  """The free-running c4_trained64 run under a kernel family; returns {step: (worst gradient error, worst parameter
+  error)} over the steps the fixture holds in full, errors relative to each reference tensor's scale."""
+  from oi_vae_amd import _lib
+  z, spec = load("c4_trained64")
+  hooks = hooks or {}
+  drift = {}
+  try:
+    _lib.set_test_hooks(OIVAE_ENC=hooks.get("OIVAE_ENC"), OIVAE_DEC=hooks.get("OIVAE_DEC"))
+    eng = _engine(spec)
+    eng.load_params(params_at(z, spec, "init/"))
+    for i in range(upto):
+      pre = "step%d/" % i
+      eng.forward_backward(z[pre + "X"], z[pre + "eps"], float(z[pre + "c"]), sigma_theta=spec["sigma_theta"], lam=spec["lam"])
+      full = (pre + "post/Ws") in z.files
+      if full:
+        got_g = dict(flat_items(eng.export_grads()))
+        ge = max(rel_err(got_g[k], b) for k, b in flat_items(params_at(z, spec, pre + "grad/")))
+      eng.adam_step(spec["lr"])
+      eng.sgd_prox_step(spec["Ws_lr"], float(z[pre + "t"]), do_prox=spec["lam"] > 0)
+      torch.cuda.synchronize()
+      assert np.array_equal(eng.zero_mask.cpu().numpy(), z[pre + "zero_mask"]), (hooks, i, "zero set")
+      if full:
+        got_p = dict(flat_items(eng.export_params()))
+        pe = max(rel_err(got_p[k], b) for k, b in flat_items(params_at(z, spec, pre + "post/")))
+        drift[i] = (ge, pe)
+  finally:
+    _lib.set_test_hooks(OIVAE_ENC=None, OIVAE_DEC=None)
+  return drift
+
+
+def test_free_running_drift_of_the_default_kernels_against_full_width_kernels():
+  """Whose drift is it?  The same 30 free-running steps under the default kernels (operands as two scaled fp16
+  terms), under the exact-operand kernels (three bf16 terms: OIVAE_ENC=bf16 OIVAE_DEC=p) and under the fp32 matrix
+  instructions (OIVAE_ENC=fp32 OIVAE_DEC=v4).  All three must keep the reference's zero set at every step, and at
+  the late steps the default kernels may not be further from the reference than 1.5 x the fp32-instruction kernels
+  are (floor: the oracle's own bar, 1e-5 of scale) -- a free-running fp32 trajectory in another summation order
+  drifts this much whatever it is computed with."""
+  runs = {"fp16x2 (default)": _trained_run(),
+          "bf16x3": _trained_run({"OIVAE_ENC": "bf16", "OIVAE_DEC": "p"}),
+          "fp32 mfma": _trained_run({"OIVAE_ENC": "fp32", "OIVAE_DEC": "v4"})}
+  print()
+  for name, d in runs.items():
+    print("free-running drift vs reference, %-17s" % name,
+          "  ".join("step %d: grads %.1e weights %.1e" % (i, g, p) for i, (g, p) in sorted(d.items())))
+  dflt, f32 = runs["fp16x2 (default)"], runs["fp32 mfma"]
+  late = (11, 12, 28, 29)
+  for i in late:   # the weights: step by step
+    assert dflt[i][1] <= 1.5 * max(f32[i][1], 1e-5), ("weights", i, dflt[i][1], f32[i][1])
+  # the gradients of a single late step scatter between the families (measured, grads at steps 12 / 28 / 29: default
+  # 2.0e-5 / 3.1e-5 / 2.7e-5, bf16x3 2.0e-5 / 1.9e-5 / 9.3e-6, fp32 instructions 1.3e-5 / 3.2e-5 / 1.2e-5 -- each is worst
+  # somewhere): the bar is on the worst of the late steps
+  assert max(dflt[i][0] for i in late) <= 1.5 * max(max(f32[i][0] for i in late), 1e-5), (dflt, f32)
+
+
+def _teacher_forced(i, mode):
+  """One step from the reference's own state after step i - 1; returns the figures after asserting the per-step bars."""
+  from oi_vae_amd import _lib
+  z, spec = load("c4_trained64")
+  prev, pre = "step%d/" % (i - 1), "step%d/" % i
+  try:
+    if mode == "fp32":
+      _lib.set_test_hooks(OIVAE_ENC="fp32", OIVAE_DEC="v4")
+    eng = _engine(spec)
+    eng.load_params(params_at(z, spec, prev + "post/"))
+    eng.load_adam_state(params_at(z, spec, prev + "adam_m/", with_Ws=False),
+                        params_at(z, spec, prev + "adam_v/", with_Ws=False), steps_done=i)
+    out = eng.forward_backward(z[pre + "X"], z[pre + "eps"], float(z[pre + "c"]), sigma_theta=spec["sigma_theta"], lam=spec["lam"])
+    torch.cuda.synchronize()
+    sc = out["scalars"].cpu().numpy()
+    for j, k in enumerate(SCALARS):
+      want = float(z[pre + k])
+      assert abs(sc[j] - want) <= 1e-5 * max(abs(want), 1.0), (i, mode, k, sc[j], want)
+    got_g = dict(flat_items(eng.export_grads()))
+    gworst = 0.0
+    for k, b in flat_items(params_at(z, spec, pre + "grad/")):
+      gworst = max(gworst, rel_err(got_g[k], b))
+      assert rel_err(got_g[k], b) < 2e-5, (i, mode, "grad", k, rel_err(got_g[k], b))
+    eng.adam_step(spec["lr"])
+    eng.sgd_prox_step(spec["Ws_lr"], float(z[pre + "t"]), do_prox=spec["lam"] > 0)
+    torch.cuda.synchronize()
+  finally:
+    _lib.set_test_hooks(OIVAE_ENC=None, OIVAE_DEC=None)
+  assert np.array_equal(eng.zero_mask.cpu().numpy(), z[pre + "zero_mask"]), (i, mode, "zero set")
+  got_p = dict(flat_items(eng.export_params()))
+  pworst, n_all, n_ok, g_all, g_ok = 0.0, 0, 0.0, 0, 0.0
+  for k, b in flat_items(params_at(z, spec, pre + "post/")):
+    pworst = max(pworst, rel_err(got_p[k], b))
+    assert rel_err(got_p[k], b) < 1e-5, (i, mode, "param", k, rel_err(got_p[k], b))
+    f, n = elementwise_within(got_p[k], b, rel=1e-5, floor=1e-3)
+    n_all += n; n_ok += f * n
+  for k, b in flat_items(params_at(z, spec, pre + "grad/")):
+    f, n = elementwise_within(got_g[k], b, rel=1e-4, floor=1e-3)
+    g_all += n; g_ok += f * n
+  print("teacher-forced step %d (%s): worst gradient %.1e, worst weight %.1e of scale; elementwise: %.4f %% of %d "
+        "weights within 1e-5 of themselves, %.3f %% of %d gradient elements within 1e-4 of themselves"
+        % (i, mode, gworst, pworst, 100 * n_ok / n_all, n_all, 100 * g_ok / g_all, g_all))
+  return dict(grad=gworst, weight=pworst, w_elem=n_ok / n_all, g_elem=g_ok / g_all)
+
+
+@pytest.mark.parametrize("i", [12, 29])
+def test_teacher_forced_steps_of_the_trained_run(i):
+  """The per-step bar where the free-running comparison is loosest: steps 12 and 29 of c4_trained64 run from the
+  REFERENCE's state after the step before -- its parameters and its Adam moments (make_golden.py `state_steps`) -- one
+  step, no trajectory: scalars 1e-5, gradients 2e-5 and post-step weights 1e-5 of each tensor's scale, zero set exact,
+  under the default kernels and under the fp32 matrix instructions.
+  Elementwise, which the normwise bars do not show: of the post-step weights that are at least 1e-3 of their tensor's
+  largest, at least 99 % are within 1e-5 of THEMSELVES, and the default kernels (two fp16 terms per operand) reach
+  the fp32-instruction kernels' fraction to a tenth of a percentage point (measured: 99.48 % both at step 12, 99.75 %
+  both at step 29 -- what is left is fp32 summation order, Adam's division by sqrt(v) included, not operand width;
+  DESIGN.md section 4)."""
+  print()
+  d = _teacher_forced(i, "default")
+  f = _teacher_forced(i, "fp32")
+  assert d["w_elem"] >= 0.99 and d["w_elem"] >= f["w_elem"] - 1e-3, (d, f)
+  assert d["g_elem"] >= f["g_elem"] - 2e-3, (d, f)
+  assert d["grad"] <= 1.5 * max(f["grad"], 2e-6) and d["weight"] <= 1.5 * max(f["weight"], 2e-7), (d, f)
