@@ -34,15 +34,32 @@ F16_MATRIX_SUSTAINED_TFLOPS = 2006.0
 PMC_FILE = os.path.join("profiles", "pmc_per_kernel_latest.json")
 
 
+DEC_SOURCES = ("oi_vae_amd/csrc/dec_x3_64s.h", "oi_vae_amd/csrc/mfma_decoder.hip", "oi_vae_amd/csrc/x3_split.h")
+
+
+def decoder_source_digest():
+  import hashlib
+  h = hashlib.sha256()
+  for f in DEC_SOURCES:
+    with open(os.path.join(ROOT, f), "rb") as fh:
+      h.update(fh.read())
+  return h.hexdigest()[:16]
+
+
 def pmc_traffic():
-  """HBM bytes per decoder launch from the committed rocprofv3 PMC passes (profiles/README.md names the commit and
-  the commands); counters cannot be read from inside this process, so this is the newest committed measurement of
-  the same kernel, not this run's."""
+  """HBM bytes per decoder launch from the committed rocprofv3 PMC passes (profiles/README.md names the commands).
+  Counters cannot be read from inside this process, so this is a committed measurement -- valid for THIS tree only if
+  it was taken from the same decoder sources: tools/pmc_summarize.py stamps the file with a digest of them, and a
+  stamp that does not match the tree's gives null (a stale figure is worse than none)."""
   try:
     d = json.load(open(os.path.join(ROOT, PMC_FILE)))
-    name, k = next((n, v) for n, v in sorted(d.items(), reverse=True) if "dec_x3_64s" in n or "dec_x3_64g" in n)
+    stamp = d.get("_decoder_source_digest")
+    if stamp != decoder_source_digest():
+      return {"bytes": None, "stale": True, "source": PMC_FILE,
+              "note": "profile taken from other decoder sources (digest %s, tree %s)" % (stamp, decoder_source_digest())}
+    name, k = next((n, v) for n, v in sorted(d.items(), reverse=True) if "dec_x3_64s" in n)
     return {"bytes": k["hbm_read_bytes_corrected"] + k["hbm_write_bytes"], "read_bytes": k["hbm_read_bytes_corrected"],
-            "write_bytes": k["hbm_write_bytes"], "kernel": name, "source": PMC_FILE}
+            "write_bytes": k["hbm_write_bytes"], "kernel": name, "source": PMC_FILE, "decoder_source_digest": stamp}
   except Exception:
     return None
 
@@ -128,6 +145,31 @@ def prox_roofline(device):
           "zeroed_fraction": float(mask.float().mean())}
 
 
+def api_leg(device, batches, rows_list, steps=10, warmup=3):
+  """The same workload through the drop-in API: `OIVAE.step` (oi_vae_amd/oivae.py, the reference's signature) on a model
+  built from the reference-shaped objects (NormalNet, 1024 group generators, BayesianGroupLassoGenerator), engine-native
+  Adam and SGD, X resident, noise drawn on the device.  ms per step at each row count."""
+  from oi_vae_amd.experiments import Experiment
+  torch.manual_seed(4321)
+  exp = Experiment(dim_x=G * DG, dim_z=K, group_dims=[DG] * G, group_input_dim=H, gen_type="mlp", hidden=M,
+                   lr=LR, Ws_lr=WS_LR, lam=LAM, device=device, device_eps=True)
+  exp.stddev_multiple = 1.0
+  exp.iteration = 2000
+  out = {}
+  for rows in rows_list:
+    xs = [b[:rows] for b in batches]
+    for i in range(warmup):
+      exp.step(xs[i % 2])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+      exp.step(xs[i % 2])
+    torch.cuda.synchronize()
+    out[str(rows)] = (time.perf_counter() - t0) / steps * 1e3
+  del exp
+  return out
+
+
 def cpu_baseline(batch=1024, steps=8):
   """The oracle (CPU restatement with the reference's per-group loop) on the host
   cores, same shapes at a reduced batch; reported, not a target."""
@@ -162,9 +204,20 @@ def main():
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    # `python bench.py --gpus N` by itself: start the N ranks as fresh child processes (one per GPU, the same command
+    # line under torch.distributed.run) and pass their output through.  Nothing in THIS process has touched the GPU --
+    # it only waits -- and nothing is exec'ed over it.
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+      sk.bind(("127.0.0.1", 0))
+      port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd).returncode)
   if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit("launch with torchrun --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
   # OIVAE_BENCH_REHEARSE=1: all ranks on cuda:0 over gloo -- walks the N > 1 code path (sharding, the two gradient
   # buckets, barriers, max over ranks, rank 0's line) on a one-GPU box; its numbers mean nothing and the line says so
   rehearse = os.environ.get("OIVAE_BENCH_REHEARSE") == "1"
@@ -284,6 +337,28 @@ def main():
     del X3
     for _ in range(2):
       step(False)
+    # the drop-in API path (OIVAE.step) beside the engine path the timed region drives, at the full batch and at an
+    # eighth of it (the per-GPU shard of an 8-GPU run, where host work per step would show first)
+    small = GLOBAL_BATCH // 8
+    xs_small = [X[:small], X2[:small]]
+    rows_saved = rows
+
+    def engine_ms(xs_, n_rows, n):
+      nonlocal rows
+      rows = n_rows
+      try:
+        for _ in range(3):
+          step(False, xs_)
+        return timed_steps(n, timed=False, xs=xs_) / n * 1e3
+      finally:
+        rows = rows_saved
+
+    extras["engine_ms_per_step"] = {str(GLOBAL_BATCH): dt / args.steps * 1e3, str(small): engine_ms(xs_small, small, 20)}
+    eng._ws_key = None
+    extras["api_ms_per_step"] = api_leg(device, batches, [GLOBAL_BATCH, small])
+    extras["api_over_engine"] = {k: extras["api_ms_per_step"][k] / extras["engine_ms_per_step"][k] for k in extras["api_ms_per_step"]}
+    for _ in range(2):
+      step(False)
     if args.sustain_seconds > 0:
       n = max(args.steps, int(args.sustain_seconds / (dt / args.steps)) + 1)
       ds = timed_steps(n, timed=False)
@@ -313,26 +388,27 @@ def main():
                  "parallelism": "dp%d" % world, "rows_per_gpu": rows},
       # the dominant kernel against the pipe it runs on: v_mfma_f32_16x16x32_f16
       "roofline": {"bound": "mfma", "kernel": "dec_x3_64s (grouped decoder fwd+bwd, fp32 products as 3 fp16 MFMAs)",
-                   "achieved": tf(f16), "peak": F16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                   "frac": tf(f16) / F16_MATRIX_PEAK_TFLOPS,
+                   "achieved": tf(alg), "peak": F16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": tf(alg) / F16_MATRIX_PEAK_TFLOPS,
                    "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
                    "avg_launch_ms": dec_avg,
-                   "issued_f16_flops_per_launch": f16,
-                   "frac_of_sustained": tf(f16) / F16_MATRIX_SUSTAINED_TFLOPS, "sustained_peak": F16_MATRIX_SUSTAINED_TFLOPS,
-                   "algorithmic_flops_per_launch": alg, "algorithmic_tflops": tf(alg),
-                   "useful_frac": tf(alg) / F16_MATRIX_PEAK_TFLOPS,
+                   "algorithmic_flops_per_launch": alg,
+                   "issued_f16_flops_per_launch": f16, "issued_tflops": tf(f16),
+                   "issued_frac": tf(f16) / F16_MATRIX_PEAK_TFLOPS,
+                   "issued_frac_of_sustained": tf(f16) / F16_MATRIX_SUSTAINED_TFLOPS, "sustained_peak": F16_MATRIX_SUSTAINED_TFLOPS,
                    "fp32_equivalent": {"executed_flops_per_launch": exe, "executed_tflops": tf(exe),
                                        "algorithmic_over_fp32_matrix_peak": tf(alg) / FP32_MATRIX_PEAK_TFLOPS,
                                        "fp32_matrix_peak": FP32_MATRIX_PEAK_TFLOPS},
-                   "note": "achieved/frac: the 16-bit matrix flops the kernel ISSUES (288 v_mfma_f32_16x16x32_f16 per "
-                           "32-row tile and group) over the dense fp16 peak; useful_frac: the reference algorithm's fp32 "
-                           "flops (9 products per group, SURVEY 8d) over the same peak -- each fp32 product costs three "
-                           "fp16 products, and W^(g) z composed with the generator's first Linear makes 6 of the 9; "
-                           "frac_of_sustained: against what the power-limited chip reaches on that instruction alone "
-                           "with random operands; fp32_equivalent: the same work priced on the fp32 matrix pipe the "
-                           "kernel does not use (round 1's frac of 2.29).  avg_launch_ms is the decoder ENTRY POINT "
-                           "timed with HIP events on its stream: dec_x3_64s plus ~0.06 ms of helpers (max|z|, the "
-                           "image of z, the range guard and its gated second launch); profiles/ holds the "
+                   "note": "achieved/frac: the reference algorithm's flops (SURVEY 8d: 3 G (2KH + 2HM + 2M D_g) per row = "
+                           "75.5 MFLOP, x rows per launch) over the launch time, against the dense fp16 matrix peak -- the "
+                           "pipe the kernel runs on.  issued_*: the 16-bit matrix flops the kernel ISSUES (288 "
+                           "v_mfma_f32_16x16x32_f16 per 32-row tile and group): each fp32 product costs three fp16 "
+                           "products, and W^(g) z composed with the generator's first Linear makes 6 products of the "
+                           "9, so issued = 2.0 x algorithmic.  issued_frac_of_sustained: against what the power-limited "
+                           "chip reaches on that instruction alone with random operands.  fp32_equivalent: the same "
+                           "work priced on the fp32 matrix pipe the kernel does not use.  avg_launch_ms is the decoder "
+                           "ENTRY POINT timed with HIP events on its stream: dec_x3_64s plus ~0.06 ms of helpers (max|z|, "
+                           "the image of z, the range guard and its gated second launch); profiles/ holds the "
                            "rocprofv3 kernel trace of the same command.  The kernel is not matrix-bound: the chain "
                            "wave's dependent sequence and the dz float atomics (8.6 GB per launch) bound it, DESIGN 3.0"},
       "step_model_tflops": (decoder_flops_per_row() + encoder_flops_per_row()) * GLOBAL_BATCH / (ms * 1e-3) / 1e12 / world,

@@ -25,7 +25,7 @@ class Experiment(object):
 
   def __init__(self, dim_x, dim_z, group_dims, group_input_dim, gen_type="linear", hidden=0,
                lr=1e-3, Ws_lr=1e-4, lam=1.0, lam_adjustment=1.0, prior_theta_scale=1.0,
-               prior_rows=1, native_optimizers=True, device=None):
+               prior_rows=1, native_optimizers=True, device=None, device_eps=False):
     assert sum(group_dims) == dim_x
     self.stddev_multiple = 0.1  # bars_data_oivae.py:60; read through the closure below on every step
     self.lam, self.lam_adjustment, self.Ws_lr = lam, lam_adjustment, Ws_lr
@@ -70,7 +70,7 @@ class Experiment(object):
     self.vae = OIVAE(
       inference_model=self.inference_net, generative_model=self.generative_net, prior_z=prior_z,
       prior_theta=NormalPriorTheta(prior_theta_scale), lam=lam,
-      optimizers=[self.optimizer, self.optimizer_Ws], device=device)
+      optimizers=[self.optimizer, self.optimizer_Ws], device=device, device_eps=device_eps)
     self.device = self.vae.engine.device
     self.elbo_per_iter = []
     self.iteration = 0

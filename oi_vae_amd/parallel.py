@@ -78,10 +78,16 @@ class BucketedGradSync:
       return
     op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
     if not self._avg and t.is_cuda:
-      # gloo with device tensors (two ranks sharing a GPU in tests and rehearsals; never the production backend):
-      # on this ROCm stack a gloo collective issued while kernels are still in flight can hang in its own stream
-      # synchronisation (seen at the 8192-row shard size; the kernels themselves had finished), so drain first
-      # and run the collective to its end before the next kernel is launched
+      # gloo with DEVICE tensors (ranks sharing a GPU in tests and rehearsals; never the production backend).  On this
+      # stack (torch 2.10.0+rocm7.0) an async gloo all-reduce of a device tensor never completes -- or crawls, 19 s a
+      # step -- when the tensor's stream still has work in flight at the moment the collective is ISSUED; with the
+      # stream idle at that moment it takes its normal 20 ms.  Established with tools/gloo_hang_probe.py
+      # (profiles/r03_gloo_hang_probe.txt): it needs no kernel of this library (one 1024^3 torch matmul in flight is
+      # enough), no second process on the GPU (rank 1 on host tensors: same), nothing launched behind the issue, no
+      # large buffer (4 KB: same) and no cold pinned staging; the same stream pattern without gloo (event, second --
+      # also high-priority -- stream waits, copy to pinned memory, host-side synchronize) runs normally with one or
+      # two processes.  So: ProcessGroupGloo's device path, not the engine's stream, not the decoder's LDS spin
+      # waits.  Draining first is the one variant that works; the collective then runs synchronously.
       torch.cuda.synchronize(t.device)
       dist.all_reduce(t, op=op, group=self.group)
       self._unscaled[which] = True

@@ -157,3 +157,21 @@ def test_adam_in_two_parts_gives_the_bits_of_one_launch():
   assert a.adam_t == b.adam_t == 3
   assert torch.equal(a.flat_params, b.flat_params)
   assert torch.equal(a.adam_m, b.adam_m) and torch.equal(a.adam_v, b.adam_v)
+
+
+def test_bench_starts_its_own_ranks_for_n_gpus():
+  """`python bench.py --gpus 2` with no launcher around it (the form the driver uses): bench.py starts the two ranks
+  itself, as fresh children under torch.distributed.run, and rank 0 prints the line.  Rehearsal mode
+  (OIVAE_BENCH_REHEARSE=1: both ranks on cuda:0 over gloo) makes that runnable on a one-GPU box: a code-path check of
+  the N > 1 bench -- sharding, the two gradient buckets, barriers, max over ranks -- whose numbers mean nothing."""
+  import json
+  env = dict(os.environ, OIVAE_BENCH_REHEARSE="1")
+  for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                     capture_output=True, text=True, timeout=380, env=env)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+  assert line["n_gpus"] == 2 and line["config"]["rows_per_gpu"] == 32768 and line["scaling"] == "strong"
+  assert "rehearsal" in line and line["comm"]["backend"] == "gloo"
+  assert line["value"] > 0 and set(line["comm"]["exposed_wait_ms"]) == {"decoder_side", "encoder"}

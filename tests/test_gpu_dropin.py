@@ -164,7 +164,8 @@ def test_evaluate_gives_the_steps_terms_without_side_effects(name):
     assert rel_err(info["q_z"].mu.cpu().numpy(), z["step0/mu_q"]) < 1e-5
   assert torch.equal(vae.engine.flat_params, before)
   assert torch.equal(vae.engine.flat_grads, grads_before)
-  assert gen.Ws.grad is None
+  # .grad is the view of the engine's gradient buffer that adopt() bound once: still there, still untouched
+  assert gen.Ws.grad.data_ptr() == vae.engine.g["Ws"].data_ptr() and float(gen.Ws.grad.abs().sum()) == 0.0
   # and a training step afterwards is still the golden one
   info = vae.step(X, float(z["step0/t"]), eps.shape[0], eps=eps)
   assert rel_err(gen.Ws.grad.cpu().numpy(), z["step0/grad/Ws"]) < 2e-5

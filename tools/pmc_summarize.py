@@ -62,6 +62,10 @@ def main():
     if "WRITE_SIZE" in e:
       e["hbm_write_bytes"] = e["WRITE_SIZE"] * 1024.0
     res[k] = e
+  # stamp: the decoder sources these counters were taken from (bench.py reports `traffic` only for a matching tree)
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  import bench
+  res["_decoder_source_digest"] = bench.decoder_source_digest()
   with open(out_path, "w") as f:
     json.dump(res, f, indent=1, sort_keys=True)
   print("wrote %s (%d kernels)" % (out_path, len(res)))
