@@ -92,9 +92,19 @@ const char* oivae_version(void);
  * scales X by it records the maximum it reads itself and is repeated (a gated second launch) when the two powers
  * of two differ, so a stale, zeroed or foreign workspace costs one more pass of that kernel, never a wrong result
  * (tests/test_gpu_ranges.py).  Passing the same workspace every step avoids the repeats.
- * A bounded wait inside the decoder kernels that runs out raises a host-visible error word: the NEXT step entry
- * point called on that device returns OIVAE_E_HIP (the earlier step's results are invalid). */
+ * A bounded wait inside the decoder kernels that runs out raises two error words, one host-visible and one on the
+ * device.  Calls are asynchronous, so the host learns of it at the first entry point it calls AFTER the kernel has
+ * run -- every entry point looks, and that call returns OIVAE_E_HIP -- which may be several calls later when the
+ * host runs ahead.  The parameters are protected regardless: oivae_adam_f32, oivae_sgd_prox_f32 and oivae_prox_f32
+ * read the device word on the device and leave their arguments untouched while it is raised, so the gradients of a
+ * failed decoder launch are never applied.  oivae_check_errors (below) gives the definite answer for everything
+ * queued so far, e.g. behind the last step of a run. */
 int64_t oivae_workspace_bytes(const oivae_shape_t* shape, int64_t B, int32_t S);
+
+/* Synchronises `stream` and reports (OIVAE_E_HIP, message in oivae_last_error) if any kernel queued on the current
+ * device before this call raised the error words; clears them.  No counterpart in the reference (its CPU path has
+ * no asynchronous failures). */
+int oivae_check_errors(void* stream);
 
 /* ---- proximal step ------------------------------------------------------
  * Replaces BayesianGroupLassoGenerator.proximal_step, lib/models.py:106-111:

@@ -47,21 +47,26 @@ static std::mutex g_init_mu;
 static uint32_t* g_err_host[kMaxDevices] = {nullptr};
 static uint32_t* g_err_dev[kMaxDevices] = {nullptr};
 
-uint32_t* error_word_device() {
+ErrWords error_words_device() {
   int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
-  return g_err_dev[dev];
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || !g_tab[dev]) return ErrWords{nullptr, nullptr};
+  return ErrWords{g_err_dev[dev], reinterpret_cast<uint32_t*>(g_tab[dev] + kBadWordOffsetU16)};
 }
 
-int poll_error_word(const char* who) {
+const uint32_t* bad_word_device() { return error_words_device().dev; }
+
+int poll_error_word(const char* who, hipStream_t stream) {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || !g_err_host[dev]) return OIVAE_OK;
   volatile uint32_t* w = g_err_host[dev];
   const uint32_t code = *w;
   if (code == 0) return OIVAE_OK;
   *w = 0;
+  // the device-resident twin: lowered behind what is already queued on the caller's stream (the update kernels of
+  // the failed step, if the host ran ahead, still find it raised)
+  (void)hipMemsetAsync(g_tab[dev] + kBadWordOffsetU16, 0, 4, stream);
   return fail(OIVAE_E_HIP, "%s: an earlier decoder launch on device %d ran out of its bounded wait for an LDS hand-over "
-              "(code %08x); the results of that step are invalid", who, dev, code);
+              "(code %08x); the results of that step are invalid and its optimizer / proximal kernels did not run", who, dev, code);
 }
 
 const uint16_t* rsqrt14_table_device() {
@@ -137,7 +142,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, float one_minus_b1, float b2,
                                                    float one_minus_b2, float step_size,
-                                                   float inv_bc2_sqrt, float eps, float gscale) {
+                                                   float inv_bc2_sqrt, float eps, float gscale,
+                                                   const uint32_t* __restrict__ bad) {
+  if (bad != nullptr && *bad != 0) return;   // a decoder launch of this step failed (common.h ErrWords): no update
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
@@ -321,7 +328,8 @@ extern "C" int oivae_init(int device) {
   OIVAE_HIP_CHECK(hipGetDevice(&prev));
   OIVAE_HIP_CHECK(hipSetDevice(device));
   uint16_t* d = nullptr;
-  hipError_t e = hipMalloc(&d, nbytes);
+  hipError_t e = hipMalloc(&d, nbytes + 256);   // + the device-resident error word (common.h ErrWords)
+  if (e == hipSuccess) e = hipMemset(reinterpret_cast<char*>(d) + nbytes, 0, 256);
   if (e == hipSuccess) e = hipMemcpy(d, oivae_rsqrt14_blob, nbytes, hipMemcpyHostToDevice);
   int rc = OIVAE_OK;
   if (e != hipSuccess) rc = fail(OIVAE_E_HIP, "oivae_init: uploading the rsqrt14 table failed: %s", hipGetErrorString(e));
@@ -340,6 +348,11 @@ extern "C" int oivae_init(int device) {
   return rc;
 }
 
+extern "C" int oivae_check_errors(void* stream) {
+  OIVAE_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return poll_error_word("oivae_check_errors", (hipStream_t)stream);
+}
+
 extern "C" int64_t oivae_workspace_bytes(const oivae_shape_t* shape, int64_t B, int32_t S) {
   if (check_shape(shape) != OIVAE_OK || B < 1 || S < 1) return -1;
   Workspace w;
@@ -352,6 +365,7 @@ extern "C" int oivae_adam_f32(float* p, const float* g, float* m, float* v, int6
                               void* stream) {
   if (!p || !g || !m || !v || n < 0 || step < 1) return fail(OIVAE_E_ARG, "oivae_adam_f32: bad argument");
   if (n == 0) return OIVAE_OK;
+  if (int rc = poll_error_word("oivae_adam_f32", (hipStream_t)stream)) return rc;
   // scalar prep in double like torch's Python-side _single_tensor_adam
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -360,7 +374,7 @@ extern "C" int oivae_adam_f32(float* p, const float* g, float* m, float* v, int6
   int64_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
-                     1.0f - beta1, beta2, 1.0f - beta2, step_size, inv_bc2_sqrt, eps, grad_scale);
+                     1.0f - beta1, beta2, 1.0f - beta2, step_size, inv_bc2_sqrt, eps, grad_scale, bad_word_device());
   OIVAE_LAUNCH_CHECK();
   return OIVAE_OK;
 }
@@ -373,7 +387,7 @@ extern "C" int oivae_finalize_f32(const oivae_shape_t* shape, const oivae_tensor
   if (!params || !grads || !out || !workspace || B < 1 || S < 1)
     return fail(OIVAE_E_ARG, "oivae_finalize_f32: bad argument");
   if (!(sigma_theta > 0.f)) return fail(OIVAE_E_ARG, "oivae_finalize_f32: sigma_theta must be > 0");
-  if (int rc = poll_error_word("oivae_finalize_f32")) return rc;
+  if (int rc = poll_error_word("oivae_finalize_f32", (hipStream_t)stream)) return rc;
   Workspace w;
   if (int rc = carve_workspace(*shape, B, S, workspace, workspace_bytes, &w)) return rc;
   hipStream_t st = (hipStream_t)stream;

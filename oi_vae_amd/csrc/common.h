@@ -31,12 +31,19 @@ inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 // Device pointer to the 65536-entry rsqrt14 table of the current device
 // (uploaded by oivae_init), or nullptr.
 const uint16_t* rsqrt14_table_device();
-// The current device's error word: one word of host-mapped memory that a kernel raises when a bounded wait inside it
-// runs out (mfma_decoder.hip lds_wait_ge).  error_word_device(): the pointer kernels take (nullptr before oivae_init);
-// poll_error_word(): called first by every step entry point -- a raised word fails THAT call with OIVAE_E_HIP (the
-// results of the launch that raised it are invalid) and is cleared.
-uint32_t* error_word_device();
-int poll_error_word(const char* who);
+// The current device's error words, raised together by a kernel whose bounded wait runs out (mfma_decoder.hip
+// lds_wait_ge): `host` is one word of host-mapped memory the library polls, `dev` its device-resident twin (behind the
+// rsqrt14 table, the allocation every proximal kernel already holds a pointer to) that the UPDATE kernels -- Adam,
+// SGD, the proximal step -- read first: with it raised they return without touching a parameter, so gradients of a
+// failed launch are never applied, however far ahead of the device the host has queued.
+// error_words_device(): what kernels take (null pointers before oivae_init).  poll_error_word(): called first by
+// every entry point -- a raised word fails THAT call with OIVAE_E_HIP, clears the host word at once and the device
+// word on `stream` (behind everything already queued there).
+struct ErrWords { uint32_t* host; uint32_t* dev; };
+ErrWords error_words_device();
+const uint32_t* bad_word_device();   // the device-resident word alone (nullptr before oivae_init)
+constexpr int kBadWordOffsetU16 = 65536;   // its place behind the 65536-entry table, in table entries
+int poll_error_word(const char* who, hipStream_t stream = nullptr);
 
 // ---- workspace layout -------------------------------------------------------
 // One flat device buffer, carved identically by every entry point.

@@ -804,7 +804,7 @@ extern "C" int oivae_encoder_fwd_f32(const oivae_shape_t* shape, const oivae_ten
   if (B < 1 || S < 1) return fail(OIVAE_E_ARG, "oivae_encoder_fwd_f32: B and S must be >= 1");
   if (prior_rows != 1 && prior_rows != B)
     return fail(OIVAE_E_ARG, "oivae_encoder_fwd_f32: prior_rows must be 1 or B (got %d, B=%lld)", prior_rows, (long long)B);
-  if (int rc = poll_error_word("oivae_encoder_fwd_f32")) return rc;
+  if (int rc = poll_error_word("oivae_encoder_fwd_f32", (hipStream_t)stream)) return rc;
   Workspace w;
   if (int rc = carve_workspace(*shape, B, S, workspace, workspace_bytes, &w)) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -837,7 +837,7 @@ extern "C" int oivae_decoder_fwd_bwd_f32(const oivae_shape_t* shape, const oivae
     return fail(OIVAE_E_ARG, "oivae_decoder_fwd_bwd_f32: null pointer");
   if (B < 1 || S < 1) return fail(OIVAE_E_ARG, "oivae_decoder_fwd_bwd_f32: B and S must be >= 1");
   const oivae_shape_t& s = *shape;
-  if (int rc = poll_error_word("oivae_decoder_fwd_bwd_f32")) return rc;
+  if (int rc = poll_error_word("oivae_decoder_fwd_bwd_f32", (hipStream_t)stream)) return rc;
   Workspace w;
   if (int rc = carve_workspace(s, B, S, workspace, workspace_bytes, &w)) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -931,7 +931,7 @@ extern "C" int oivae_encoder_bwd_f32(const oivae_shape_t* shape, const oivae_ten
   if (B < 1 || S < 1) return fail(OIVAE_E_ARG, "oivae_encoder_bwd_f32: B and S must be >= 1");
   if (prior_rows != 1 && prior_rows != B) return fail(OIVAE_E_ARG, "oivae_encoder_bwd_f32: prior_rows must be 1 or B");
   const oivae_shape_t& s = *shape;
-  if (int rc = poll_error_word("oivae_encoder_bwd_f32")) return rc;
+  if (int rc = poll_error_word("oivae_encoder_bwd_f32", (hipStream_t)stream)) return rc;
   Workspace w;
   if (int rc = carve_workspace(s, B, S, workspace, workspace_bytes, &w)) return rc;
   return encoder_bwd_run(s, grads, X, B, S, eps, c, prior_mu, prior_sigma, prior_rows, mu_q, sig_q, ea, dz, w.dpre,

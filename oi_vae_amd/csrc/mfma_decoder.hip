@@ -57,7 +57,7 @@ struct MfmaDecArgs {
   const uint32_t* rng;   // dec_x3_64g: [0] max|X| the scales assume, [5] max|z|
   uint32_t* rng_seen;    // dec_x3_64g: max|x| of what the kernel read (atomicMax), or nullptr
   const uint32_t* gate;  // gated launch: returns at once when *gate == 0 (nullptr: always runs)
-  uint32_t* err;         // the library's error word (host-mapped), raised by a timed-out LDS wait
+  ErrWords err;          // the library's error words (host-mapped + device-resident), raised by a timed-out LDS wait
   int G;
   float* acc2;           // dec_x3_64s: second-level slabs of the weight-gradient waves (nullptr: short launches, no second level)
 };
@@ -1309,14 +1309,17 @@ constexpr int kX3DecLdsP = kX3DecLds + 64;
 #ifndef OIVAE_TEST_WAIT_LIMIT
 #define OIVAE_TEST_WAIT_LIMIT (1 << 22)
 #endif
-__device__ __forceinline__ void lds_wait_ge(const volatile uint32_t* f, uint32_t v, volatile uint32_t* err) {
+__device__ __forceinline__ void lds_wait_ge(const volatile uint32_t* f, uint32_t v, const ErrWords& err) {
   int guard = 0;
   // the counter lives in LDS: read it as such (through the generic pointer it is a flat load, which also waits for
   // every global load in flight)
   const volatile __attribute__((address_space(3))) uint32_t* fl = (const volatile __attribute__((address_space(3))) uint32_t*)f;
   while (__builtin_amdgcn_readfirstlane(*fl) < v) {
     if (++guard >= OIVAE_TEST_WAIT_LIMIT) {
-      if (err != nullptr && (threadIdx.x & 63) == 0) *err = 0x4c445357u;   // "LDSW"
+      if (err.host != nullptr && (threadIdx.x & 63) == 0) {   // "LDSW"
+        *(volatile uint32_t*)err.dev = 0x4c445357u;    // first the word the update kernels read, then the host's
+        *(volatile uint32_t*)err.host = 0x4c445357u;
+      }
       break;
     }
     __builtin_amdgcn_s_sleep(1);
@@ -2587,7 +2590,7 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   const bool use_s = use_g && (dec_env == nullptr || dec_env[0] == 's');   // dec_x3_64s: the same kernel on 16x16x32 instructions (default)
   uint32_t* rng = w.ranges;
   a.G = s.G;
-  a.err = error_word_device();
+  a.err = error_words_device();
   a.gate = nullptr;
   a.rng_seen = nullptr;
   if (all64 && (use_x3 || use_g)) {

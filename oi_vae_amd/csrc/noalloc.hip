@@ -42,6 +42,7 @@ extern "C" int oivae_encoder_bwd_noalloc_f32(const oivae_shape_t* shape, const o
   if (B < 1 || S < 1) return fail(OIVAE_E_ARG, "oivae_encoder_bwd_noalloc_f32: B and S must be >= 1");
   if (prior_rows != 1 && prior_rows != B)
     return fail(OIVAE_E_ARG, "oivae_encoder_bwd_noalloc_f32: prior_rows must be 1 or B");
+  if (int rc = poll_error_word("oivae_encoder_bwd_noalloc_f32", (hipStream_t)stream)) return rc;
   const oivae_shape_t& s = *shape;
   int dev = -1;
   OIVAE_HIP_CHECK(hipGetDevice(&dev));

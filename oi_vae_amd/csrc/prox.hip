@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void prox_rows_scalar(float* __restrict__ Ws,
                                                         uint8_t* __restrict__ mask,
                                                         float* __restrict__ norms,
                                                         const uint16_t* __restrict__ tab) {
+  if (*reinterpret_cast<const uint32_t*>(tab + kBadWordOffsetU16) != 0) return;   // a decoder launch of this step failed: no update (common.h ErrWords)
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   float* w = Ws + r * H;
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256) void prox_rows_vec(float* __restrict__ Ws,
                                                      uint8_t* __restrict__ mask,
                                                      float* __restrict__ norms,
                                                      const uint16_t* __restrict__ tab) {
+  if (*reinterpret_cast<const uint32_t*>(tab + kBadWordOffsetU16) != 0) return;   // a decoder launch of this step failed: no update (common.h ErrWords)
   constexpr int H = 8 * V;
   const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t r = gt >> 1;
@@ -232,6 +234,7 @@ __global__ __launch_bounds__(kProxLdsThreads, 1) void prox_rows_vec_lds(float* _
                                                                         uint8_t* __restrict__ mask,
                                                                         float* __restrict__ norms,
                                                                         const uint16_t* __restrict__ tab) {
+  if (*reinterpret_cast<const uint32_t*>(tab + kBadWordOffsetU16) != 0) return;   // a decoder launch of this step failed: no update (common.h ErrWords)
   constexpr int H = 8 * V;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint16_t* ltab = reinterpret_cast<uint16_t*>(smem_raw);   // [65536]
@@ -294,6 +297,7 @@ __global__ __launch_bounds__(256) void prox_rows_wide(float* __restrict__ Ws, co
                                                       int64_t rows, int H, float neg_lr, float t, int do_prox,
                                                       uint8_t* __restrict__ mask, float* __restrict__ norms,
                                                       const uint16_t* __restrict__ tab) {
+  if (*reinterpret_cast<const uint32_t*>(tab + kBadWordOffsetU16) != 0) return;   // a decoder launch of this step failed: no update (common.h ErrWords)
   const int sub = threadIdx.x & 31;                                    // chain: accumulator k = sub / 8, lane l = sub % 8
   const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   const bool live = r < rows;                                           // uniform per group of 32
@@ -500,6 +504,7 @@ extern "C" int oivae_prox_f32(float* Ws, int64_t rows, int32_t H, float t, uint8
   if (H < 1 || H > (1 << 20))
     return fail(OIVAE_E_SHAPE, "oivae_prox_f32: H=%d outside [1, 2^20] (the reference's row-sum order is pinned only there)", H);
   if (rows * 2 / 256 > 0x7fffffffLL) return fail(OIVAE_E_SHAPE, "oivae_prox_f32: too many rows");
+  if (int rc = poll_error_word("oivae_prox_f32", (hipStream_t)stream)) return rc;
   return launch_prox<false>(Ws, nullptr, rows, H, 0.f, t, 1, zero_mask, row_norms, (hipStream_t)stream);
 }
 
@@ -510,6 +515,7 @@ extern "C" int oivae_sgd_prox_f32(float* Ws, const float* dWs, int64_t rows, int
   if (H < 1 || H > (1 << 20))
     return fail(OIVAE_E_SHAPE, "oivae_sgd_prox_f32: H=%d outside [1, 2^20]", H);
   if (rows * 2 / 256 > 0x7fffffffLL) return fail(OIVAE_E_SHAPE, "oivae_sgd_prox_f32: too many rows");
+  if (int rc = poll_error_word("oivae_sgd_prox_f32", (hipStream_t)stream)) return rc;
   return launch_prox<true>(Ws, dWs, rows, H, lr, t, do_prox ? 1 : 0, zero_mask, row_norms, (hipStream_t)stream);
 }
 

@@ -311,6 +311,14 @@ class Engine:
         grad_sync.encoder_grads_ready()
     return dict(mu_q=mu_q, sig_q=sig_q, z=z, scalars=self.scalars, X=X, eps=eps)
 
+  def check_errors(self):
+    """Waits for everything queued on the current stream and raises OivaeError if a kernel reported a failure on the
+    device (a decoder hand-over that timed out).  The step itself never waits: parameters are protected on the
+    device (the update kernels refuse to run behind a failed launch) and the host hears of it at its next call;
+    this is the definite answer, e.g. behind the last step of a run."""
+    with torch.cuda.device(self.device):
+      _lib.check(self.lib.oivae_check_errors(self._stream()), "oivae_check_errors")
+
   def _const(self, name, val):
     t = self._bufs.get(name)
     if t is None:
