@@ -36,8 +36,10 @@ def sample_many_bars_images(num_images, image_size, row_mul, col_mul):
   """[num_images, image_size^2]: each row and column lit with probability mul / image_size.
   (The reference's own version of this function raises on torch >= 1.x: it calls .view(-1)
   on a non-contiguous sum.)"""
-  p_row = torch.full((image_size,), float(row_mul) / image_size)
-  p_col = torch.full((image_size,), float(col_mul) / image_size)
+  # the probabilities in the reference's fp32 association, (1 / n) * mul: rounding mul / n once instead differs by an
+  # ulp for some (n, mul) -- e.g. n = 7, mul = 3 -- and a Bernoulli draw compares against exactly this number
+  unit = torch.ones(image_size) / image_size
+  p_row, p_col = unit * row_mul, unit * col_mul
   draws = [_bar_draws(p_row, p_col) for _ in range(num_images)]       # the reference's draw order
   rows = torch.stack([r for r, _ in draws])                           # [num_images, image_size]
   cols = torch.stack([c for _, c in draws])

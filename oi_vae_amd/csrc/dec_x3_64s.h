@@ -156,7 +156,10 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
         rs += __shfl_xor(rs, 2);
         rs += __shfl_xor(rs, 4);
         if (part == 0) {
-          const float gb = sC3[d] * (rs + fabsf(sb2[d]) + __uint_as_float(a.rng[0]));
+          // max|X| enters as the upper edge of its binade, 2^(E+1): that is all the range guard verifies about the
+          // recorded maximum, so the scales -- and with them the result's bits -- depend on nothing else of it
+          const float xedge = __uint_as_float(((a.rng[0] & 0x7f800000u) < 0x7f000000u ? (a.rng[0] & 0x7f800000u) + 0x00800000u : 0x7f000000u));
+          const float gb = sC3[d] * (rs + fabsf(sb2[d]) + xedge);
           gbound[d] = gb;
           gmx = gb;
         }

@@ -63,8 +63,11 @@ class Gamma(object):
     return self._dist().sample()
 
   def logprob(self, x):
-    """Sum over all elements of log Gamma(x; shape, rate)."""
-    return self._dist().log_prob(x).sum()
+    """Sum over all elements of log Gamma(x; shape, rate) = a log b - lgamma(a) + (a - 1) log x - b x, the four terms
+    added in that order (lib/distributions.py:65-70): the same bits as the reference, and its NaN at x = 0 with
+    shape 1 (0 * log 0), which torch.distributions' xlogy would turn into 0."""
+    a, b = self.shape, self.rate
+    return torch.sum(a * torch.log(b) - torch.lgamma(a) + (a - 1) * torch.log(x) - b * x)
 
 
 class _DistributionCat(object):

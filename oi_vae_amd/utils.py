@@ -31,5 +31,7 @@ def KL_Normals(d0, d1):
   if d0.mu.shape != d1.mu.shape:
     raise AssertionError("KL_Normals: shapes differ: %s vs %s" % (tuple(d0.mu.shape), tuple(d1.mu.shape)))
   var0, var1 = d0.sigma * d0.sigma, d1.sigma * d1.sigma
-  per_element = (var0 + (d0.mu - d1.mu) ** 2) / (2 * var1) + torch.log(d1.sigma / d0.sigma) - 0.5
+  # term order as lib/utils.py:13-18 adds them (fp32 sums are order-sensitive), and the two logarithms kept apart:
+  # log(s1 / s0) over- or underflows where log s1 - log s0 does not
+  per_element = -0.5 + (var0 + (d0.mu - d1.mu) ** 2) / (2 * var1) + torch.log(d1.sigma) - torch.log(d0.sigma)
   return per_element.sum()

@@ -89,6 +89,33 @@ def test_amc_write_read_round_trip(tmp_path):
   assert np.array_equal(arr[:, 3:], seq)                              # %.9g round-trips fp32 exactly
 
 
+def test_bars_probabilities_keep_the_reference_association():
+  """n = 7, mul = 3: fl(fl(1/7) * 3) != fl(3/7).  The Bernoulli draws compare uniform numbers against the probability,
+  so the stream only equals the reference's (lib/bars_data.py:16-23) with its association of the two roundings."""
+  import torch
+  p_ref = torch.ones(7) / 7 * 3.0
+  assert float(p_ref[0]) != float(torch.tensor(3.0 / 7))
+  torch.manual_seed(5)
+  want = torch.stack([0.5 * (torch.bernoulli(p_ref).unsqueeze(1) + torch.bernoulli(p_ref).unsqueeze(0)).reshape(-1)
+                      for _ in range(200)])
+  torch.manual_seed(5)
+  assert torch.equal(bars_data.sample_many_bars_images(200, 7, 3.0, 3.0), want)
+
+
+def test_kl_normals_keeps_the_two_logarithms_apart():
+  import torch
+  from oi_vae_amd.distributions import Normal
+  from oi_vae_amd.utils import KL_Normals
+  d0 = Normal(torch.zeros(1, 2), torch.tensor([[1e-30, 1e25]]))
+  d1 = Normal(torch.zeros(1, 2), torch.tensor([[1e25, 1e-30]]))
+  assert torch.isinf(torch.log(d1.sigma / d0.sigma)).any()      # the quotient leaves fp32's range ...
+  assert torch.isfinite(torch.log(d1.sigma) - torch.log(d0.sigma)).all()
+  mu, s = torch.randn(3, 4), torch.rand(3, 4) + 0.1
+  got = KL_Normals(Normal(mu, s), Normal(torch.zeros(3, 4), torch.ones(3, 4)))
+  want = torch.sum(-0.5 + (torch.pow(s, 2) + torch.pow(mu, 2)) / 2 + 0.0 - torch.log(s))
+  assert got.item() == want.item()
+
+
 def test_distribution_classes_match_reference_vectors():
   """Gamma / Normal / _DistributionCat log-probabilities against values recorded from the
   reference's classes (tests/golden/make_golden_dist.py) and, for Gamma, scipy's closed form."""
@@ -99,9 +126,8 @@ def test_distribution_classes_match_reference_vectors():
   v = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dist_vectors.npz"))
   t = lambda k: torch.from_numpy(v[k])
   got = Gamma(t("gamma_shape"), t("gamma_rate")).logprob(t("gamma_x")).item()
-  # the reference sums shape*log(rate) - lgamma(shape) + (shape-1)*log(x) - rate*x in fp32; ours goes through
-  # torch.distributions.Gamma (same terms, other association): 1e-6 relative, and float64 scipy below
-  assert abs(got - float(v["gamma_logprob"])) <= 1e-6 * abs(float(v["gamma_logprob"]))
+  # same four fp32 terms in the same order as the reference: the same bits; float64 scipy below
+  assert got == float(v["gamma_logprob"])
   want = scipy.stats.gamma.logpdf(v["gamma_x"].astype(np.float64), v["gamma_shape"].astype(np.float64),
                                   scale=1.0 / v["gamma_rate"].astype(np.float64)).sum()
   assert abs(got - want) < 1e-4 * abs(want)

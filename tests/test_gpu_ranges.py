@@ -92,6 +92,31 @@ def test_decoder_after_x_changed_in_place(factor):
   _close(_decoder(eng, X, z, B, S, ws), want, 5e-6, (factor, "second call: ranges corrected by the first"))
 
 
+def test_decoder_bits_do_not_depend_on_a_stale_maximum_of_the_same_binade():
+  """The guard accepts a recorded max|X| that shares its power of two with the maximum the kernel reads.  The scales
+  must then depend on that power of two alone: a decoder call after a forward call of ANOTHER X with a different
+  maximum in the same binade gives, bit for bit, what it gives after a forward call of its own X (every tensor but dz,
+  whose float atomics are order-dependent in the last bits)."""
+  B, S = 128, 1
+  g = torch.Generator(device="cuda").manual_seed(8)
+  X = torch.rand(B, G * 64, generator=g, device="cuda") * 0.6 + 0.05        # max just under 0.65: binade [0.5, 1)
+  Xo = torch.rand(B, G * 64, generator=g, device="cuda") * 0.93 + 0.05     # max just under 0.98: same binade
+  assert 0.5 <= float(X.max()) < float(Xo.max()) < 1.0
+  eps = torch.randn(S, B, K, generator=g, device="cuda")
+  z = torch.randn(B * S, K, generator=g, device="cuda")
+  res = []
+  for first in (X, Xo):
+    eng = _engine(47)
+    eng._ws_key = None
+    ws = eng._workspace(B, S)
+    ws.zero_()
+    _fwd(eng, first, eps, ws)                    # leaves max|first| in the workspace's ranges
+    res.append(_decoder(eng, X, z, B, S, ws))
+  for n in DEC:
+    assert torch.equal(res[0][n], res[1][n]), n
+  _close(res[1], _decoder_ref64(eng, X, z, B, S), 5e-6, "stale same-binade maximum")
+
+
 def test_decoder_on_a_workspace_that_never_saw_a_forward_call():
   B, S = 97, 1
   eng = _engine(43)
