@@ -294,6 +294,11 @@ __global__ __launch_bounds__(768, 1) void enc_x3_gemm(const float* __restrict__ 
 constexpr int kH2Row = 20;
 constexpr int kH2Sub = 128 * kH2Row + 16;   // sub-step images 16 banks apart (stores bank over 32 dwords): the producers' stores stay conflict-free
 constexpr int kH2Buf = 4 * kH2Sub;
+// Second level of the consumers' running sums (H2Consumer16): 64 registers x 64 lanes of fp32 per consumer wave behind
+// the two macro-tile buffers, and the number of macro tiles (reduction steps of 32) between two moves into it.
+constexpr int kH2Acc2Floats = 4 * 64 * 64;
+constexpr int kH2FlushTiles = 64;
+constexpr size_t kH2LdsBytes = sizeof(uint32_t) * 2 * kH2Buf + sizeof(float) * kH2Acc2Floats;
 
 // max|v| over one array, or over two of the same length (blockIdx.y), into one word
 __global__ __launch_bounds__(256) void absmax_f32(const float* __restrict__ v0, const float* __restrict__ v1, int64_t n,
@@ -424,8 +429,27 @@ struct H2Consumer16 {
   u32x4 pa[2][2][2], pb[2][2][2];   // [half][16-row block][term]
   const uint32_t* a0;
   const uint32_t* b0;
-  __device__ __forceinline__ void init(const uint32_t* lds, int wm, int wn, int lane) {
+  // The matrix instruction aligns its products to the largest addend, the accumulator, and drops what falls below its
+  // window: over a reduction of 65536 (2048 macro tiles) the lo x hi terms are partly lost against the grown running
+  // sum (dec_x3_64s.h has the measurement).  Every kH2FlushTiles tiles the 64 accumulators are added -- by vector
+  // adds, rounded to nearest -- into a wave-private image in LDS and start from zero again.
+  float* l2;
+  bool has2;
+  __device__ __forceinline__ void flush() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4* q = reinterpret_cast<f32x4*>(l2) + (i * 4 + j) * 64;
+        *q = has2 ? *q + acc[i][j] : acc[i][j];
+        acc[i][j] = (f32x4)(0.f);
+      }
+    has2 = true;
+  }
+  __device__ __forceinline__ void init(uint32_t* lds, int wm, int wn, int lane) {
     const int l15 = lane & 15, kb = lane >> 4;
+    l2 = reinterpret_cast<float*>(lds + 2 * kH2Buf) + (wm * 2 + wn) * (64 * 64) + lane * 4;
+    has2 = false;
     const int off = (kb & 1) * kH2Sub + 4 * (kb >> 1);
     a0 = lds + (wm * 64 + h2_pi16(l15)) * kH2Row + off;
     b0 = lds + 2 * kH2Sub + (wn * 64 + h2_pi16(l15)) * kH2Row + off;
@@ -501,6 +525,7 @@ struct H2Consumer16 {
       __syncthreads();  // P_t
       odd_tile(1);
       __syncthreads();  // P_{t+1}
+      if (((t + 2) & (kH2FlushTiles - 1)) == 0 && t + 2 < T) flush();   // (the tile's last product, still to be issued, joins the next sum)
     }
     if (t < T) {
       even_tile(0);
@@ -510,6 +535,12 @@ struct H2Consumer16 {
       mm<1, 1>();
     }
     for (int u = T; u < Tr; ++u) __syncthreads();
+    if (has2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += reinterpret_cast<const f32x4*>(l2)[(i * 4 + j) * 64];
+    }
   }
   // output (16-row block I, 16-column block Jb, register i) of lane: tile row / tile column inside the wave's 64 x 64
   __device__ __forceinline__ static int out_row(int I, int i, int lane) { return 16 * I + h2_pi16(4 * (lane >> 4) + i); }
@@ -929,7 +960,7 @@ int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params,
                          params->enc_Wsig, s.K, J, s.D, Jp, KT, wimg, rng);
       OIVAE_LAUNCH_CHECK();
     }
-    const size_t lds2 = sizeof(uint32_t) * 2 * kH2Buf;
+    const size_t lds2 = kH2LdsBytes;
     OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_h2_fwd_gemm),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     hipLaunchKernelGGL(enc_h2_fwd_gemm, grid, dim3(768), lds2, st, X, B, s.D, J, wimg, KT, pre, klen, rng,
@@ -971,7 +1002,7 @@ int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, 
     hipLaunchKernelGGL(h2_split_cols, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, dpre, B, J, Jp, BT, img,
                        (const uint32_t*)colmax);
     OIVAE_LAUNCH_CHECK();
-    const size_t lds = sizeof(uint32_t) * 2 * kH2Buf;
+    const size_t lds = kH2LdsBytes;
     OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_h2_bwd_gemm),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const dim3 grid((unsigned)(s.D / 128), (unsigned)(Jp / 128), 1);

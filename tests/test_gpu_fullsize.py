@@ -7,7 +7,7 @@
   * MEG at its real size (configs[2]: 44 ragged sensor regions, D = 8184, K = 10, H = 1, B = 4096): one whole step
     (gradients, Adam, SGD, proximal step) against the live CPU oracle.
 
-Tolerances are the north star's: scalars 1e-5 relative, gradients 2e-5 and post-step weights 1e-5 of the tensor's
+Tolerances are the north star's: scalars 1e-5 relative, gradients 1e-5 (the bar is 2e-5; float64 shows 1e-6) and post-step weights 1e-5 of the tensor's
 scale -- per REFERENCE tensor, i.e. per group for the generator tensors (the reference keeps one tensor per group)."""
 import numpy as np
 import pytest
@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 SCALARS = ("z_kl", "loglik_term", "logprob_theta", "logprob_W", "loss", "elbo")
 
 
-def _check_against_f64(eng, X, eps, c, out, tag, rows_per_chunk, gtol=2e-5):
+def _check_against_f64(eng, X, eps, c, out, tag, rows_per_chunk, gtol=1e-5):   # (measured: 1e-6 everywhere but the dead groups' dW2, 5.5e-6)
   sc, ref = f64_step(eng, X, eps, c, rows_per_chunk=rows_per_chunk)
   got = out["scalars"].double().cpu().numpy()
   for j, k in enumerate(SCALARS):
