@@ -127,6 +127,7 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
   w->ranges = reinterpret_cast<uint32_t*>(take(256));
   w->enc_bwd_part = reinterpret_cast<float*>(take(enc_bwd_part_bytes(s, B, x3_encoder_bwd_applies(s, B))));
   w->x3_z = reinterpret_cast<uint32_t*>(take((plan.mfma && s.K == 64) ? ((N + 31) / 32) * 24 * 1024 : 0));
+  w->dec_zmax = reinterpret_cast<uint32_t*>(take((plan.mfma && s.K == 64) ? 1024 : 0));
   {
     const int64_t a2 = plan.mfma ? mfma_decoder_acc2_bytes(s, N, plan.chunks) : 0;
     w->dec_acc2 = a2 > 0 ? reinterpret_cast<float*>(take(a2)) : nullptr;
@@ -168,15 +169,15 @@ struct ThetaSegs {
   int64_t n[4];
 };
 
-__global__ __launch_bounds__(256) void theta_prior_kernel(ThetaSegs sg, float inv_var, double* __restrict__ part) {
-  __shared__ double sm[256];
+__device__ __forceinline__ void theta_prior_block(const ThetaSegs& sg, float inv_var, double* __restrict__ part,
+                                                  int bx, int nbx, double* sm) {
   const int q = blockIdx.y;
   const float* __restrict__ th = sg.th[q];
   float* __restrict__ gr = sg.gr[q];
   const int64_t n = sg.n[q];
   double acc = 0.0;
-  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  int64_t i = ((int64_t)bx * blockDim.x + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)nbx * blockDim.x * 4;
   const bool vec = ((reinterpret_cast<uintptr_t>(th) | reinterpret_cast<uintptr_t>(gr)) & 15) == 0;
   for (; i < n; i += stride) {
     if (vec && i + 4 <= n) {
@@ -199,20 +200,19 @@ __global__ __launch_bounds__(256) void theta_prior_kernel(ThetaSegs sg, float in
     if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) part[(int64_t)q * gridDim.x + blockIdx.x] = sm[0];
+  if (threadIdx.x == 0) part[(int64_t)q * nbx + bx] = sm[0];
 }
 
 // sum over rows of ||Ws[row, :]||_2.  L lanes per row (a power of two, 16 bytes per lane and pass) when rows are
 // 16-byte aligned -- a wave then reads whole rows back to back instead of 64 rows 4 H bytes apart -- else one thread
 // per row.
-__global__ __launch_bounds__(256) void penalty_kernel(const float* __restrict__ Ws, int64_t rows, int H, int L,
-                                                      double* __restrict__ part) {
-  __shared__ double sm[256];
+__device__ __forceinline__ void penalty_block(const float* __restrict__ Ws, int64_t rows, int H, int L,
+                                              double* __restrict__ part, int bx, int nbx, double* sm) {
   double acc = 0.0;
   if (L > 0) {
     const int sub = threadIdx.x & (L - 1);
-    int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / L;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x / L;
+    int64_t r = ((int64_t)bx * blockDim.x + threadIdx.x) / L;
+    const int64_t stride = (int64_t)nbx * blockDim.x / L;
     const int64_t rounds = (rows + stride - 1) / stride;   // every lane of a row group runs the same number of passes
     for (int64_t it = 0; it < rounds; ++it, r += stride) {
       float s = 0.f;
@@ -227,8 +227,8 @@ __global__ __launch_bounds__(256) void penalty_kernel(const float* __restrict__ 
       if (sub == 0 && r < rows) acc += (double)sqrtf(s);
     }
   } else {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t r = (int64_t)bx * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)nbx * blockDim.x;
     for (; r < rows; r += stride) {
       const float* w = Ws + r * H;
       float s = 0.f;
@@ -242,7 +242,21 @@ __global__ __launch_bounds__(256) void penalty_kernel(const float* __restrict__ 
     if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+  if (threadIdx.x == 0) part[bx] = sm[0];
+}
+
+// One launch for both (they were two; at an 8-GPU shard every launch is 5 us of a 2.4 ms step): rows 0..3 of the grid
+// are the weight prior over the four generator parameter arrays, row 4 the penalty; a row uses the first nbx_* of the
+// grid's columns.
+__global__ __launch_bounds__(256) void prior_penalty_kernel(ThetaSegs sg, float inv_var, double* __restrict__ theta_part,
+                                                            int nbx_theta, const float* __restrict__ Ws, int64_t rows,
+                                                            int H, int L, double* __restrict__ pen_part, int nbx_pen) {
+  __shared__ double sm[256];
+  if (blockIdx.y < 4) {
+    if ((int)blockIdx.x < nbx_theta) theta_prior_block(sg, inv_var, theta_part, blockIdx.x, nbx_theta, sm);
+  } else if ((int)blockIdx.x < nbx_pen) {
+    penalty_block(Ws, rows, H, L, pen_part, blockIdx.x, nbx_pen, sm);
+  }
 }
 
 // sums the partial arrays in index order (deterministic) and writes the scalars
@@ -407,15 +421,15 @@ extern "C" int oivae_finalize_f32(const oivae_shape_t* shape, const oivae_tensor
     sg.th[q] = th[q]; sg.gr[q] = gr[q]; sg.n[q] = cnt[q];
     n_theta_elems += (double)cnt[q];
   }
-  hipLaunchKernelGGL(theta_prior_kernel, dim3((unsigned)(w.n_theta / 4), 4), dim3(256), 0, st, sg, inv_var, w.theta_part);
-  OIVAE_LAUNCH_CHECK();
   const int64_t rows = (int64_t)s.G * s.K;
   int pen_lanes = 0;   // lanes per row: the largest power of two <= min(64, H / 4)
   if (s.H % 4 == 0 && (reinterpret_cast<uintptr_t>(params->Ws) & 15) == 0) {
     pen_lanes = 1;
     while (pen_lanes * 2 <= s.H / 4 && pen_lanes < 64) pen_lanes *= 2;
   }
-  hipLaunchKernelGGL(penalty_kernel, dim3((unsigned)w.n_pen), dim3(256), 0, st, params->Ws, rows, s.H, pen_lanes, w.pen_part);
+  const int nbx_theta = w.n_theta / 4;
+  hipLaunchKernelGGL(prior_penalty_kernel, dim3((unsigned)(nbx_theta > w.n_pen ? nbx_theta : w.n_pen), 5), dim3(256), 0, st,
+                     sg, inv_var, w.theta_part, nbx_theta, params->Ws, rows, s.H, pen_lanes, w.pen_part, w.n_pen);
   OIVAE_LAUNCH_CHECK();
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, w.kl_part, w.n_kl, w.ll_part, w.n_ll,
                      w.theta_part, w.n_theta, w.pen_part, w.n_pen, n_theta_elems, sigma_theta, lam,

@@ -63,6 +63,7 @@ struct Workspace {
   uint32_t* x3_img;                        // x3 encoder: split image of the weights (fwd) / of dpre (bwd)
   uint32_t* ranges;                        // 64 words: operand maxima of the fp16 kernels (x3_encoder.hip "ranges")
   float*  enc_bwd_part;                    // fp32 matrix-core encoder backward: [slices][2K][D] partial images (few-tile shapes)
+  uint32_t* dec_zmax;                      // dec_x3_64s/g: 256 per-workgroup maxima of |z| (dec_absmax_f32 -> x3_split_z)
   float*  dec_acc2;                        // dec_x3_64s: second-level slabs of its weight-gradient waves (nullptr: not needed)
   int64_t total_bytes;
 };

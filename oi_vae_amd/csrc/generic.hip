@@ -843,8 +843,8 @@ extern "C" int oivae_decoder_fwd_bwd_f32(const oivae_shape_t* shape, const oivae
   hipStream_t st = (hipStream_t)stream;
   const int64_t N = B * (int64_t)S;
   const DecPlan pl = plan_decoder(s, N);
+  if (pl.mfma) return launch_decoder_mfma(s, params, grads, X, B, S, z, gen_sig_off, dz, w, st);   // (zeroes dz itself)
   OIVAE_HIP_CHECK(hipMemsetAsync(dz, 0, sizeof(float) * N * s.K, st));
-  if (pl.mfma) return launch_decoder_mfma(s, params, grads, X, B, S, z, gen_sig_off, dz, w, st);
   if (pl.flat) return launch_decoder_flat(s, params, grads, X, B, S, z, gen_sig_off, dz, w, st);
   if (pl.R == 0 && !pl.single)
     return fail(OIVAE_E_SHAPE, "oivae_decoder_fwd_bwd_f32: group weights do not fit LDS (K=%d H=%d M=%d)", s.K, s.H, s.M);

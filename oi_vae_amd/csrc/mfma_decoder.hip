@@ -934,7 +934,8 @@ constexpr int kX3DecLds = (4 * 6144 + 192 + 3 * 64 * 65) * 4;  // images | b1, b
 
 __device__ __forceinline__ int x3_slot_feature(int ks, int hh, int e) { return 16 * ks + 8 * (e >> 2) + 4 * hh + (e & 3); }
 
-__global__ __launch_bounds__(256) void dec_absmax_f32(const float* __restrict__ v, int64_t n, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void dec_absmax_f32(const float* __restrict__ v, int64_t n, uint32_t* __restrict__ out,
+                                                      int per_block) {
   float m = 0.f;
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
   if ((reinterpret_cast<uintptr_t>(v) & 15) == 0) {   // 16 bytes per lane, scalar tail
@@ -953,7 +954,11 @@ __global__ __launch_bounds__(256) void dec_absmax_f32(const float* __restrict__ 
   __shared__ float part[4];   // one atomic per workgroup: thousands of atomics on one address take 14 ns each
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
+  if (threadIdx.x == 0) {
+    const uint32_t mx = __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
+    if (per_block) out[blockIdx.x] = mx;   // one slot per workgroup, every slot written: nothing to zero first
+    else atomicMax(out, mx);
+  }
 }
 
 // Split image of z for dec_x3_64, shared by all groups: per 32-row tile 24 fragments of 1 KB,
@@ -963,10 +968,25 @@ __global__ __launch_bounds__(256) void dec_absmax_f32(const float* __restrict__ 
 // lay16 (dec_x3_64s, 16x16x32 instructions; two fp16 terms only): lane (c = lane & 15, q = lane >> 4),
 //   [0..3]  (kk, nb): row 16 nb + c, slot e <-> latent 32 kk + 8 q + e
 //   [4..7]  kb: latent 16 kb + c, slot e <-> row 8 q + e
+// dec_x3_64g / dec_x3_64s (rng != nullptr) fold two more jobs into this launch (each was a 5 us memset before): the
+// maximum of z is reduced here from the kZmaxParts per-workgroup maxima dec_absmax_f32 left (every workgroup reduces
+// them for itself; workgroup 0 also writes rng[5] = max|z| and lowers rng[6], rng[7] for the decoder kernel that
+// follows), and dz -- N x 64 floats, one float4 per thread of this launch -- is zeroed.
+constexpr int kZmaxParts = 256;
 __global__ __launch_bounds__(256) void x3_split_z(const float* __restrict__ z, int64_t N, uint32_t* __restrict__ img,
-                                                  const uint32_t* __restrict__ rng, int lay16) {
+                                                  uint32_t* __restrict__ rng, int lay16,
+                                                  const uint32_t* __restrict__ zmax_parts, float* __restrict__ dz) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t tiles = (N + 31) / 32;
+  uint32_t zmax = 0;
+  if (rng != nullptr) {
+    const int l = threadIdx.x & 63;
+    zmax = max(max(zmax_parts[l], zmax_parts[64 + l]), max(zmax_parts[128 + l], zmax_parts[192 + l]));   // bit patterns of non-negative floats order like the floats
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) zmax = max(zmax, (uint32_t)__shfl_xor((int)zmax, o));
+    if (i == 0) { rng[5] = zmax; rng[6] = 0; rng[7] = 0; }
+    if (i < N * 16) reinterpret_cast<x3_f32x4*>(dz)[i] = (x3_f32x4)(0.f);
+  }
   if (i >= tiles * 512) return;
   const int64_t tile = i >> 9;
   const int grp = (int)(i >> 6) & 7, lane = (int)i & 63, l31 = lane & 31, hh = lane >> 5;
@@ -1004,7 +1024,7 @@ __global__ __launch_bounds__(256) void x3_split_z(const float* __restrict__ z, i
   }
   if (rng != nullptr) {   // dec_x3_64g: two fp16 terms of z * 2^e in fragments 2 grp, 2 grp + 1 (both orientations)
     float sz, iz;
-    h2_scale_of(rng[5], &sz, &iz);
+    h2_scale_of(zmax, &sz, &iz);
     const Frag2 f2 = split8_h2(v[0] * sz, v[1] * sz, v[2] * sz, v[3] * sz, v[4] * sz, v[5] * sz, v[6] * sz, v[7] * sz);
 #pragma unroll
     for (int p = 0; p < 2; ++p) *reinterpret_cast<x3_u32x4*>(img + ((tile * 24 + grp * 2 + p) * 64 + lane) * 4) = f2.p[p];
@@ -2600,12 +2620,15 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
     if (!w.x3_z) return fail(OIVAE_E_WORKSPACE, "x3 decoder: no z image in the workspace");
     const int64_t zt = (N + 31) / 32;
     if (use_g) {
-      OIVAE_HIP_CHECK(hipMemsetAsync(rng + 5, 0, 12, st));   // [5] max|z|, [6] max|x| the kernel reads, [7] redo flag
-      hipLaunchKernelGGL(dec_absmax_f32, dim3(256), dim3(256), 0, st, z, N * 64, rng + 5);
+      // [5] max|z|, [6] max|x| the kernel reads, [7] redo flag: set by x3_split_z from the per-workgroup maxima
+      if (!w.dec_zmax) return fail(OIVAE_E_WORKSPACE, "x3 decoder: no room for the maxima of z in the workspace");
+      hipLaunchKernelGGL(dec_absmax_f32, dim3(kZmaxParts), dim3(256), 0, st, z, N * 64, w.dec_zmax, 1);
       OIVAE_LAUNCH_CHECK();
+    } else {
+      OIVAE_HIP_CHECK(hipMemsetAsync(dz, 0, sizeof(float) * N * s.K, st));
     }
     hipLaunchKernelGGL(x3_split_z, dim3((unsigned)((zt * 512 + 255) / 256)), dim3(256), 0, st, z, N, w.x3_z,
-                       use_g ? rng : (const uint32_t*)nullptr, use_s ? 1 : 0);
+                       use_g ? rng : (uint32_t*)nullptr, use_s ? 1 : 0, (const uint32_t*)w.dec_zmax, dz);
     OIVAE_LAUNCH_CHECK();
     a.zimg = w.x3_z;
     a.rng = rng;
@@ -2639,6 +2662,7 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
     OIVAE_LAUNCH_CHECK();
     rc = OIVAE_OK;
   } else if (all64 && !force_v1 && N * (int64_t)s.K * 4 < (int64_t)1 << 32) {
+    OIVAE_HIP_CHECK(hipMemsetAsync(dz, 0, sizeof(float) * N * s.K, st));
     const size_t lds = (size_t)(3 * 64 * 65 + 4 * 64 + 4 * 3 * 32 * 68) * sizeof(float);
     OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_mfma64_v4),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2647,6 +2671,7 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
     rc = OIVAE_OK;
   } else {
     // dimension-generic kernel: one instantiation per combination of 32 / 64
+    OIVAE_HIP_CHECK(hipMemsetAsync(dz, 0, sizeof(float) * N * s.K, st));
     rc = fail(OIVAE_E_SHAPE, "MFMA decoder: unsupported dims K=%d H=%d M=%d D_g=%d", s.K, s.H, s.M, s.uniform_group_dim);
 #define OIVAE_DEC_ONE(KK, HH, MM, DD) \
     if (s.K == KK && s.H == HH && s.M == MM && s.uniform_group_dim == DD) rc = launch_one<KK, HH, MM, DD>(a, s.G, chunks, st);

@@ -295,11 +295,18 @@ class Engine:
       _lib.check(self._timed("decoder", lambda: L.oivae_decoder_fwd_bwd_f32(
         sh, pt, gt, X.data_ptr(), B, S, z.data_ptr(), float(gen_sig_off),
         dz.data_ptr(), ws.data_ptr(), self._ws_bytes, st)), "oivae_decoder_fwd_bwd_f32")
-      _lib.check(self._timed("finalize", lambda: L.oivae_finalize_f32(
-        sh, pt, gt, B, S, float(sigma_theta), float(lam), self.scalars.data_ptr(),
-        ws.data_ptr(), self._ws_bytes, st)), "oivae_finalize_f32")
+      def finalize(stream_ptr):
+        _lib.check(self._timed("finalize", lambda: L.oivae_finalize_f32(
+          sh, pt, gt, B, S, float(sigma_theta), float(lam), self.scalars.data_ptr(),
+          ws.data_ptr(), self._ws_bytes, stream_ptr)), "oivae_finalize_f32")
       if evaluate_only:
+        finalize(st)
         return dict(mu_q=mu_q, sig_q=sig_q, z=z, scalars=self.scalars, X=X, eps=eps)
+      # (Tried: these three small kernels on a side stream BESIDE the encoder backward's own small kernels -- dpre, bias
+      # sums, column maxima, the image of dpre^T -- so that the two idle stretches overlap: 2.545 against 2.513 ms per step
+      # at 8192 rows, slower; the two cross-stream event waits cost more than the 30 us they hide.  A HIP graph of the
+      # whole sequence replays in exactly the eager time, tools/graph_probe.py: the host is never the bound.)
+      finalize(st)
       if grad_sync is not None:
         grad_sync.decoder_grads_ready()
       _lib.check(self._timed("encoder_bwd", lambda: L.oivae_encoder_bwd_f32(
