@@ -246,6 +246,33 @@ int oivae_adam_f32(float* p, const float* g, float* m, float* v, int64_t n,
                    float lr, float beta1, float beta2, float eps, int32_t step,
                    float grad_scale, void* stream);
 
+/* ---- the whole step of a small model in one launch ------------------------------------------------------------
+ * Replaces OIVAE.step (lib/oivae.py:42-90) in one call for the shapes the reference's own scripts train
+ * (bars_data_oivae.py:20-33, mo_mo_mocap_oivae.py:26-35): encoder forward + KL + samples, grouped decoder forward /
+ * backward + log-likelihood, weight prior, penalty, the six scalars, encoder backward and -- with do_optimizers --
+ * Adam over every non-Ws parameter (bars_data_oivae.py:233-239), SGD on Ws and, with do_prox, the proximal step
+ * (lib/oivae.py:76-79), the last two bit for bit as oivae_sgd_prox_f32.  One memset node and one kernel instead of the
+ * two dozen launches of the entry points above (which stay valid for the same shapes and give the same results to
+ * rounding; these models are launch-bound).  `grads` is written completely either way; mu_q, sig_q [B,K], z [S*B,K]
+ * and `out` hold the PRE-update values (lib/oivae.py:81-90).  adam_m / adam_v: Adam's moments, one array per tensor
+ * in the layout of `params` (Ws entries unused); adam_step >= 1 is the step being taken.  The four tensor sets must
+ * share one memory layout (every tensor at the same element offset from its set's enc_Wmu, enc_Wmu lowest: one flat
+ * buffer each, as the host mirror keeps them), else OIVAE_E_ARG.  Float sums are formed in a
+ * fixed order: results are bit-reproducible run to run.
+ * Accepted (oivae_small_step_applies says 1): single-layer generators (OIVAE_GEN_LINEAR, OIVAE_GEN_TANH_LINEAR),
+ * H in {1,2,4,8}, K <= 32, D <= 256, groups of at most 16 outputs, S <= 64, S*B <= 8192, at most 2^17 parameters;
+ * else OIVAE_E_SHAPE.  Workspace: oivae_workspace_bytes(shape, B, S). */
+int oivae_small_step_applies(const oivae_shape_t* shape, int64_t B, int32_t S);
+int oivae_small_step_f32(const oivae_shape_t* shape, const oivae_tensors_t* params, const oivae_tensors_t* grads,
+                         const float* X, int64_t B, int32_t S, const float* eps, float c, float sig_off,
+                         const float* prior_mu, const float* prior_sigma, int32_t prior_rows,
+                         float gen_sig_off, float sigma_theta, float lam,
+                         float* mu_q, float* sig_q, float* z, oivae_scalars_t* out,
+                         int32_t do_optimizers, const oivae_tensors_t* adam_m, const oivae_tensors_t* adam_v,
+                         float lr, float beta1, float beta2, float adam_eps, int32_t adam_step,
+                         float ws_lr, float t, int32_t do_prox, uint8_t* zero_mask, float* row_norms,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ SYMBOLS = [
   "oivae_prox_f32", "oivae_sgd_prox_f32", "oivae_prox_cols_f32", "oivae_encoder_fwd_f32",
   "oivae_decoder_fwd_bwd_f32", "oivae_encoder_bwd_f32", "oivae_finalize_f32",
   "oivae_adam_f32", "oivae_encoder_bwd_noalloc_f32", "oivae_dz_layout", "oivae_reload_test_hooks",
-  "oivae_check_errors",
+  "oivae_check_errors", "oivae_small_step_applies", "oivae_small_step_f32",
 ]
 
 
@@ -82,6 +82,12 @@ def bind(path):
                                               c_vp, c_vp, c_vp, c_vp, c_vp]
   L.oivae_finalize_f32.argtypes = [PS, PT, PT, c_i64, c_i32, c_f, c_f, c_vp, c_vp, c_i64, c_vp]
   L.oivae_adam_f32.argtypes = [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_i32, c_f, c_vp]
+  L.oivae_small_step_applies.argtypes = [PS, c_i64, c_i32]
+  L.oivae_small_step_applies.restype = ctypes.c_int
+  L.oivae_small_step_f32.argtypes = [PS, PT, PT, c_vp, c_i64, c_i32, c_vp, c_f, c_f, c_vp, c_vp, c_i32, c_f, c_f, c_f,
+                                     c_vp, c_vp, c_vp, c_vp, c_i32, PT, PT, c_f, c_f, c_f, c_f, c_i32,
+                                     c_f, c_f, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]
+  L.oivae_small_step_f32.restype = ctypes.c_int
   L.oivae_check_errors.argtypes = [c_vp]
   L.oivae_check_errors.restype = ctypes.c_int
   L.oivae_reload_test_hooks.argtypes = []

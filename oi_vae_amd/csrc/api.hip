@@ -127,6 +127,7 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
   w->ranges = reinterpret_cast<uint32_t*>(take(256));
   w->enc_bwd_part = reinterpret_cast<float*>(take(enc_bwd_part_bytes(s, B, x3_encoder_bwd_applies(s, B))));
   w->x3_z = reinterpret_cast<uint32_t*>(take((plan.mfma && s.K == 64) ? ((N + 31) / 32) * 24 * 1024 : 0));
+  w->small = take(plan_small_step(s, B, S).ws_bytes);
   w->dec_zmax = reinterpret_cast<uint32_t*>(take((plan.mfma && s.K == 64) ? 1024 : 0));
   {
     const int64_t a2 = plan.mfma ? mfma_decoder_acc2_bytes(s, N, plan.chunks) : 0;
@@ -149,12 +150,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    const float gi = g[i] * gscale;
-    float mi = m[i], vi = v[i];
-    mi = mi + one_minus_b1 * (gi - mi);           // exp_avg.lerp_(grad, 1-beta1)
-    vi = b2 * vi + one_minus_b2 * gi * gi;        // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
-    p[i] = p[i] - step_size * (mi / denom);
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_update_dev(pi, g[i] * gscale, mi, vi, one_minus_b1, b2, one_minus_b2, step_size, inv_bc2_sqrt, eps);
+    p[i] = pi;
     m[i] = mi;
     v[i] = vi;
   }

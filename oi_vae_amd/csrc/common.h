@@ -64,6 +64,7 @@ struct Workspace {
   uint32_t* ranges;                        // 64 words: operand maxima of the fp16 kernels (x3_encoder.hip "ranges")
   float*  enc_bwd_part;                    // fp32 matrix-core encoder backward: [slices][2K][D] partial images (few-tile shapes)
   uint32_t* dec_zmax;                      // dec_x3_64s/g: 256 per-workgroup maxima of |z| (dec_absmax_f32 -> x3_split_z)
+  char*   small;                           // small_step.hip: per-block gradient slabs, KL / log-lik partials, ticket counter
   float*  dec_acc2;                        // dec_x3_64s: second-level slabs of its weight-gradient waves (nullptr: not needed)
   int64_t total_bytes;
 };
@@ -107,6 +108,9 @@ struct DecPlan {
 
 DecPlan plan_decoder(const oivae_shape_t& s, int64_t N);
 int64_t mfma_decoder_acc2_bytes(const oivae_shape_t& s, int64_t N, int chunks);   // mfma_decoder.hip
+// small_step.hip: the whole step of a small model in one launch
+struct SmallPlan { bool ok; int RB, NR, GR, nblk; int64_t P; int64_t ws_bytes; size_t lds_bytes; };
+SmallPlan plan_small_step(const oivae_shape_t& s, int64_t B, int32_t S);
 
 // flat (many-small-groups) decoder, flat_decoder.hip
 struct FlatLayout { int64_t oHc, oWc, oWk, oCt, oDzp, oImgA, oImgB, oImgC, total; int splits; bool h2; };
@@ -157,6 +161,21 @@ int encoder_bwd_run(const oivae_shape_t& s, const oivae_tensors_t* grads, const 
 #if defined(__HIPCC__)
 __device__ __forceinline__ void atomic_max_if_larger(uint32_t* p, uint32_t v) {
   if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) atomicMax(p, v);
+}
+#endif
+#if defined(__HIPCC__)
+// torch.optim.Adam's element update (default options) as adam_kernel (api.hip) and the small-model step kernel
+// (small_step.hip) apply it; contraction as in api.hip's translation unit whatever the including one's flags are.
+__device__ __forceinline__ void adam_update_dev(float& p, float g, float& m, float& v, float one_minus_b1, float b2,
+                                                float one_minus_b2, float step_size, float inv_bc2_sqrt, float eps) {
+#pragma clang fp contract(fast)
+  float mi = m, vi = v;
+  mi = mi + one_minus_b1 * (g - mi);           // exp_avg.lerp_(grad, 1-beta1)
+  vi = b2 * vi + one_minus_b2 * g * g;         // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+  const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+  p = p - step_size * (mi / denom);
+  m = mi;
+  v = vi;
 }
 #endif
 inline int enc_bias_blocks(int64_t B) { const int64_t bb = (B + 15) / 16; return (int)(bb > kBiasBlocks ? kBiasBlocks : bb); }

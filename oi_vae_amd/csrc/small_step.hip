@@ -1,0 +1,540 @@
+// The whole training step of a SMALL oi-VAE in one launch: the shapes the reference's own scripts train
+// (bars_data_oivae.py: 8 groups of 8 pixels, K = 8..16, H = 1, batch 64; mo_mo_mocap_oivae.py: 29 joints of 1..3
+// angles, K = 8, H = 8, batch 64 x 10 samples).  At these sizes the step of the large-model kernels is two dozen
+// launches of 4..8 us each -- launch-bound at 0.11 ms; here it is one memset node and one kernel:
+//
+//   every workgroup takes RB batch rows (with their S samples: NR = RB S decoder rows) through
+//     encoder forward + reparameterisation + KL            lib/models.py:15-16, lib/utils.py:9-18, lib/oivae.py:50-53
+//     grouped decoder forward + log-likelihood + backward  lib/models.py:91-95, lib/distributions.py:40-45
+//     encoder backward                                     lib/oivae.py:75
+//   and leaves its share of every gradient in a slab of its own and its KL / log-likelihood sums in two slots (no
+//   float atomics: the step is bit-reproducible run to run);
+//   the workgroup that finishes LAST (a ticket counter) then adds the slabs in workgroup order, adds the weight
+//   prior's term and value (lib/oivae.py:15-23), the penalty (lib/models.py:113-114) and the six scalars
+//   (lib/oivae.py:50-71), and -- when the caller's optimizers are the engine's -- applies Adam (bars_data_oivae.py:
+//   233-239), SGD on Ws and the proximal step (lib/oivae.py:76-79, lib/models.py:106-111; bit-exact: prox_dev.h).
+//
+// Single-layer generators only (Linear | Tanh -> Linear), H in {1, 2, 4, 8}; the limits are in plan_small_step.
+// Built with -ffp-contract=off like prox.hip (the proximal step's arithmetic is pinned); products that may fuse are
+// written as fmaf.
+#include "common.h"
+#include "prox_dev.h"
+
+namespace oivae {
+
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallDgMax = 16;    // widest group
+constexpr int kSmallKMax = 32;
+constexpr int kSmallDMax = 256;
+constexpr int kSmallMaxBlocks = 32;
+constexpr int64_t kSmallMaxParams = 12288;   // every parameter is staged in LDS (48 KB)
+
+static inline int64_t small_param_count(const oivae_shape_t& s) {
+  return 2 * ((int64_t)s.K * s.D + s.K) + (int64_t)s.D * s.H + 2 * (int64_t)s.D + (int64_t)s.G * s.K * s.H;
+}
+
+SmallPlan plan_small_step(const oivae_shape_t& s, int64_t B, int32_t S) {
+  SmallPlan p{};
+  p.ok = false;
+  if (test_hooks().force_generic) return p;
+  if (s.gen_type == OIVAE_GEN_MLP) return p;
+  if (!(s.H == 1 || s.H == 2 || s.H == 4 || s.H == 8)) return p;
+  if (s.K > kSmallKMax || s.D > kSmallDMax || s.max_group_dim > kSmallDgMax) return p;
+  if (S < 1 || S > 64 || B < 1 || B * (int64_t)S > 8192) return p;
+  const int64_t P = small_param_count(s);
+  if (P > kSmallMaxParams) return p;
+  // few, fat workgroups: the step is latency-bound (a handful of dependent phases), and the last workgroup adds one
+  // slab per workgroup -- about 48 decoder rows each, one (row, group) item per thread in the decoder phase
+  const int64_t N = B * (int64_t)S;
+  int nb = (int)((N + 47) / 48);   // (24, 48, 96, 192 rows tried: bars 35 / 34 / 40 / 44 us per step, mocap 61 / 59 / 79 / 99)
+  if (nb < 1) nb = 1;
+  int RB = (int)((B + nb - 1) / nb);
+  if (RB * S > kSmallThreads) RB = kSmallThreads / S;
+  if (RB < 1) return p;
+  const int NR = RB * S;
+  if ((B + RB - 1) / RB > kSmallMaxBlocks) return p;
+  int GR = kSmallThreads / NR;               // groups per round
+  if (GR > s.G) GR = s.G;
+  p.RB = RB; p.NR = NR; p.GR = GR; p.nblk = (int)((B + RB - 1) / RB); p.P = P;
+  // LDS floats: all parameters | X rows | pre / dpre | mu, sig, ea | z | dz | gmu | act, dH
+  // (row strides of the tiles that lanes walk by rows are odd: K | 1, D | 1, ...: LDS bank conflicts were most of the time)
+  const size_t fl = (size_t)P + (size_t)RB * (s.D | 1) + (size_t)RB * 2 * s.K + 3 * (size_t)RB * s.K + 2 * (size_t)NR * (s.K | 1) +
+                    (size_t)NR * GR * (s.max_group_dim | 1) + 2 * (size_t)NR * GR * (s.H | 1);
+  p.lds_bytes = fl * sizeof(float) + 64;
+  if (p.lds_bytes > 140 * 1024) return p;
+  p.ws_bytes = align_up((int64_t)sizeof(float) * P * p.nblk, 256) + 2 * align_up((int64_t)sizeof(double) * p.nblk, 256) + 256 +
+               (int64_t)sizeof(unsigned long long) * 16 * kSmallMaxBlocks;
+  p.ok = true;
+  return p;
+}
+
+struct SmallArgs {
+  int D, K, G, H, tanh_gen, DGS;   // DGS: the widest group = row stride of the staged d mu tile
+  const int32_t* group_off;
+  int64_t B;
+  int S, RB, NR, GR, nblk;
+  float *P0, *G0, *M0, *V0;   // the four tensor sets share ONE layout: base pointers + foff (element offsets of the eight tensors)
+  int foff[8];
+  const float* X;
+  const float* eps;
+  float c, sig_off, gen_sig_off;
+  const float* prior_mu;
+  const float* prior_sigma;
+  int prior_stride;     // 0: one prior row broadcast, K: one per batch row
+  float* mu_q;
+  float* sig_q;
+  float* z;
+  float sigma_theta, lam;
+  oivae_scalars_t* out;
+  int do_opt;           // 1: Adam + SGD (+ proximal step when do_prox) in the same launch
+  float one_minus_b1, b2, one_minus_b2, step_size, inv_bc2_sqrt, adam_eps;
+  float neg_ws_lr, t;
+  int do_prox;
+  uint8_t* mask;
+  float* norms;
+  const uint16_t* tab;
+  float* slab;
+  int64_t P;
+  double* kl_part;
+  double* ll_part;
+  uint32_t* counter;
+  unsigned long long* stamps;
+  int64_t oWmu, obmu, oWsig, obsig, oW2, ob2, oLs, oWs;   // offsets inside a slab
+};
+
+// What this kernel's time is made of (wall_clock64 stamps, tools/small_step_probe.py): latency, not arithmetic.  In the
+// order found: LDS bank conflicts (row strides of 8, 16, 64 floats walked by lanes: the encoder forward alone took
+// 32 us; strides are odd now and lanes walk rows), global loads inside dependent loops (every parameter is staged
+// in LDS first), LDS latency in un-unrolled reduction loops (unrolled by 8), then code bytes -- every instruction runs
+// about once on a CU that has most likely never seen it: 32-bit index arithmetic, select chains instead of pointer
+// tables, and the hardware's exp2 / log2 / rcp instead of expf / logf / tanhf (1e-7-grade absolute error, as the
+// large-model kernels').
+__device__ __forceinline__ float s_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float s_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float s_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(s_exp(2.0f * x) + 1.0f); }
+
+// two block-wide sums at once: wave shuffles, then the 16 waves' partials through LDS in wave order (fixed order)
+__device__ __forceinline__ void block_sum2(double& x, double& y, double* sm) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { x += __shfl_xor(x, o); y += __shfl_xor(y, o); }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[2 * w] = x; sm[2 * w + 1] = y; }
+  __syncthreads();
+  double sx = 0.0, sy = 0.0;
+#pragma unroll 8
+  for (int i = 0; i < kSmallThreads / 64; ++i) { sx += sm[2 * i]; sy += sm[2 * i + 1]; }
+  __syncthreads();
+  x = sx; y = sy;
+}
+
+// slab offset / offset inside the caller's tensor sets of tensor q (slab order: Wmu, bmu, Wsig, bsig, W2, b2, log_sigma,
+// Ws), by a chain of selects: tables indexed at run time would live in scratch memory, unrolled loops over them would
+// cost code bytes, and forty pointers as kernel arguments spill the scalar registers (a thousand v_readlane)
+#define OIVAE_OFF(q) ((q) == 0 ? oWmu : (q) == 1 ? obmu : (q) == 2 ? oWsig : (q) == 3 ? obsig : (q) == 4 ? oW2 : (q) == 5 ? ob2 : \
+                      (q) == 6 ? oLs : oWs)
+#define OIVAE_FOFF(q) ((q) == 0 ? a.foff[0] : (q) == 1 ? a.foff[1] : (q) == 2 ? a.foff[2] : (q) == 3 ? a.foff[3] : \
+                       (q) == 4 ? a.foff[4] : (q) == 5 ? a.foff[5] : (q) == 6 ? a.foff[6] : a.foff[7])
+#define OIVAE_SEG(i) (((i) >= obmu) + ((i) >= oWsig) + ((i) >= obsig) + ((i) >= oW2) + ((i) >= ob2) + ((i) >= oLs) + ((i) >= oWs))
+
+#ifdef OIVAE_SMALL_STAMPS   // phase timing for tools/small_step_probe.py (scratch builds only): wall_clock64 at the phase boundaries
+#define OIVAE_STAMP(i) do { if (threadIdx.x == 0) a.stamps[(int64_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define OIVAE_STAMP(i) do { } while (0)
+#endif
+
+template <int H>
+__global__ __launch_bounds__(kSmallThreads) void small_step_kernel(SmallArgs a) {
+  if (*reinterpret_cast<const uint32_t*>(a.tab + kBadWordOffsetU16) != 0) return;   // common.h ErrWords
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ double sm[2 * kSmallThreads / 64];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, blk = blockIdx.x;
+  const int D = a.D, K = a.K, G = a.G, RB = a.RB, NR = a.NR, GR = a.GR, S = a.S;
+  const int B = (int)a.B;      // (S B <= 8192: everything below indexes with 32 bits)
+  const int r0 = blk * RB;
+  const int P32 = (int)a.P;
+  const int oWmu = (int)a.oWmu, obmu = (int)a.obmu, oWsig = (int)a.oWsig, obsig = (int)a.obsig, oW2 = (int)a.oW2,
+            ob2 = (int)a.ob2, oLs = (int)a.oLs, oWs = (int)a.oWs;
+  float* Ps = reinterpret_cast<float*>(smem_raw);          // every parameter, in the slab's order (global loads inside the
+  const float* pWmu = Ps + oWmu; const float* pbmu = Ps + obmu;   // phases' dependent loops cost a microsecond each)
+  const float* pWsig = Ps + oWsig; const float* pbsig = Ps + obsig;
+  const float* pW2 = Ps + oW2; const float* pb2 = Ps + ob2; const float* pLs = Ps + oLs; const float* pWs = Ps + oWs;
+  const int DP = D | 1, KP = K | 1;                          // odd row strides: lanes that walk rows meet different banks
+  constexpr int HP = H | 1;
+  float* Xs = Ps + P32;                                      // [RB][DP]
+  float* pre = Xs + RB * DP;                                  // [RB][2K]  pre-activations, later their gradients
+  float* mus = pre + RB * 2 * K;                             // [RB][K]
+  float* sgs = mus + RB * K;
+  float* eas = sgs + RB * K;
+  float* zs = eas + RB * K;                                  // [NR][KP]  local row n = s RB + r
+  float* dzs = zs + NR * KP;                                 // [NR][KP]
+  const int DGS = a.DGS | 1;
+  float* gmuS = dzs + NR * KP;                               // [GR NR][DGS]  d(-loglik / (S B)) / d mu
+  float* actS = gmuS + NR * GR * DGS;                        // [GR NR][HP]
+  float* dHS = actS + NR * GR * HP;
+  float* slab = a.slab + blk * P32;
+  const float inv = 1.0f / ((float)S * (float)B);
+  const float invB = 1.0f / (float)B;
+
+  OIVAE_STAMP(0);
+  // ---- X rows of this workgroup (rows past the batch read as zeros and are masked everywhere below) ----
+  for (int o = tid; o < RB * D; o += kSmallThreads) {
+    const int r = o / D, d = o - r * D;
+    Xs[r * DP + d] = (r0 + r < B) ? a.X[(r0 + r) * D + d] : 0.f;
+  }
+  for (int o = tid; o < NR * KP; o += kSmallThreads) dzs[o] = 0.f;
+  for (int i = tid; i < P32; i += kSmallThreads) {   // every parameter into LDS, packed in the slab's order
+    const int q = OIVAE_SEG(i);
+    Ps[i] = a.P0[OIVAE_FOFF(q) + i - OIVAE_OFF(q)];
+  }
+  __syncthreads();
+  // ---- encoder forward: pre[r][j] = b_j + sum_d X[r][d] W[j][d], j < K the mu head, j >= K the sigma head ----
+  for (int o = tid; o < RB * 2 * K; o += kSmallThreads) {
+    const int j = o / RB, r = o - j * RB;      // lanes walk the rows: one weight row broadcast, X rows an odd stride apart
+    const float* W = (j < K) ? pWmu + j * D : pWsig + (j - K) * D;
+    float acc = (j < K) ? pbmu[j] : pbsig[j - K];
+    const float* x = Xs + r * DP;
+#pragma unroll 8
+    for (int d = 0; d < D; ++d) acc = __builtin_fmaf(x[d], W[d], acc);
+    pre[r * 2 * K + j] = acc;
+  }
+  __syncthreads();
+  OIVAE_STAMP(1);
+  double kl = 0.0;
+  for (int o = tid; o < RB * K; o += kSmallThreads) {
+    const int r = o / K, k = o - r * K;
+    const float mu = pre[r * 2 * K + k];
+    const float ea = s_exp(pre[r * 2 * K + K + k]);
+    const float sg = ea * a.c + a.sig_off;
+    mus[o] = mu; sgs[o] = sg; eas[o] = ea;
+    const bool live = r0 + r < B;
+    if (live) {
+      const float mp = a.prior_mu[(r0 + r) * a.prior_stride + k], sp = a.prior_sigma[(r0 + r) * a.prior_stride + k];
+      const float dm = mu - mp;
+      kl += (double)(-0.5f + (sg * sg + dm * dm) / (2.0f * (sp * sp)) + s_log(sp) - s_log(sg));   // lib/utils.py:13-18
+      a.mu_q[(r0 + r) * K + k] = mu;
+      a.sig_q[(r0 + r) * K + k] = sg;
+    }
+    for (int s = 0; s < S; ++s) {
+      const float e = live ? a.eps[((s * B) + r0 + r) * K + k] : 0.f;
+      const float zv = __builtin_fmaf(sg, e, mu);
+      zs[(s * RB + r) * KP + k] = zv;
+      if (live) a.z[((s * B) + r0 + r) * K + k] = zv;
+    }
+  }
+  __syncthreads();
+  OIVAE_STAMP(2);
+  // ---- decoder, GR groups per round: item = (decoder row n, group) per thread, then one output per thread ----
+  double ll = 0.0;
+  const int n_it = tid % NR, gi_it = tid / NR, r_it = n_it % RB;
+  const bool row_live = r0 + r_it < B;
+  for (int g0 = 0; g0 < G; g0 += GR) {
+    const int gcur = (G - g0 < GR) ? G - g0 : GR;
+    if (gi_it < gcur) {
+      const int g = g0 + gi_it;
+      const float* Wsg = pWs + g * K * H;
+      const float* zr = zs + n_it * KP;
+      float h[H], act[H], dt[H];
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) { h[hh] = 0.f; dt[hh] = 0.f; }
+#pragma unroll 4
+      for (int k = 0; k < K; ++k) {
+        const float zk = zr[k];
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) h[hh] = __builtin_fmaf(zk, Wsg[k * H + hh], h[hh]);
+      }
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) act[hh] = a.tanh_gen ? s_tanh(h[hh]) : h[hh];
+      const int o0 = a.group_off[g], dg = a.group_off[g + 1] - o0;
+      float* gm = gmuS + tid * DGS;
+      for (int d = 0; d < dg; ++d) {
+        const int col = o0 + d;
+        const float sig = s_exp(pLs[col]) + a.gen_sig_off;
+        float mu = pb2[col];
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) mu = __builtin_fmaf(pW2[col * H + hh], act[hh], mu);
+        const float q = (Xs[r_it * DP + col] - mu) / sig;
+        const float gmv = row_live ? -(q / sig) * inv : 0.f;                    // d(-loglik / (S B)) / d mu
+        if (row_live) ll += (double)(-0.5f * kLog2Pi - s_log(sig) - 0.5f * (q * q));   // lib/distributions.py:41-45
+        gm[d] = gmv;
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) dt[hh] = __builtin_fmaf(pW2[col * H + hh], gmv, dt[hh]);
+      }
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) {
+        const float dh = a.tanh_gen ? dt[hh] * (1.0f - act[hh] * act[hh]) : dt[hh];
+        actS[tid * HP + hh] = act[hh];
+        dHS[tid * HP + hh] = dh;
+        dt[hh] = dh;
+      }
+    }
+    __syncthreads();
+    if (g0 == 0) OIVAE_STAMP(9);
+    // outputs of the round: per group K H of dWs, dg H of dW2, dg of db2, dg of dlog_sigma -- sums over the NR rows --
+    // and this round's share of dz, [NR][K]: sums over the round's groups and hidden units, in a fixed order
+    const int cmax = K * H + DGS * H + 2 * DGS;
+    for (int o = tid; o < gcur * cmax + NR * K; o += kSmallThreads) {
+      if (o >= gcur * cmax) {
+        const int e = o - gcur * cmax, k = e / NR, n = e - k * NR;   // lanes walk the rows
+        float sacc = dzs[n * KP + k];
+        for (int gi = 0; gi < gcur; ++gi) {
+          const float* Wr = pWs + ((g0 + gi) * K + k) * H;
+          const float* dh = dHS + (gi * NR + n) * HP;
+#pragma unroll
+          for (int hh = 0; hh < H; ++hh) sacc = __builtin_fmaf(Wr[hh], dh[hh], sacc);
+        }
+        dzs[n * KP + k] = sacc;
+        continue;
+      }
+      const int gi = o / cmax, idx = o - gi * cmax, g = g0 + gi;
+      const int o0 = a.group_off[g], dg = a.group_off[g + 1] - o0;
+      const int base = gi * NR;
+      float sacc = 0.f;
+      if (idx < K * H) {
+        const int k = idx / H, hh = idx - k * H;
+        #pragma unroll 8
+        for (int n = 0; n < NR; ++n) sacc = __builtin_fmaf(zs[n * KP + k], dHS[(base + n) * HP + hh], sacc);
+        slab[oWs + (g * K + k) * H + hh] = sacc;
+      } else if (idx < K * H + DGS * H) {
+        const int e = idx - K * H, d = e / H, hh = e - d * H;
+        if (d < dg) {
+#pragma unroll 8
+          for (int n = 0; n < NR; ++n) sacc = __builtin_fmaf(gmuS[(base + n) * DGS + d], actS[(base + n) * HP + hh], sacc);
+          slab[oW2 + (o0 + d) * H + hh] = sacc;
+        }
+      } else if (idx < K * H + DGS * H + DGS) {
+        const int d = idx - K * H - DGS * H;
+        if (d < dg) {
+#pragma unroll 8
+          for (int n = 0; n < NR; ++n) sacc += gmuS[(base + n) * DGS + d];
+          slab[ob2 + o0 + d] = sacc;
+        }
+      } else {
+        const int d = idx - K * H - DGS * H - DGS;
+        if (d < dg) {
+          // L = inv sum_n [log sigma + q^2 / 2], q = (x - mu) / sigma = -(d mu) sigma / inv:
+          // dL/dlog_sigma = inv e / sigma (rows - sum_n q^2), sigma = e + offset
+          int rows_live = 0;
+#pragma unroll 8
+          for (int n = 0; n < NR; ++n) { const float gv = gmuS[(base + n) * DGS + d]; sacc = __builtin_fmaf(gv, gv, sacc); }
+          for (int r = 0; r < RB; ++r) rows_live += (r0 + r < B) ? S : 0;
+          const float e = s_exp(pLs[o0 + d]);
+          const float sig = e + a.gen_sig_off;
+          const float sumq2 = sacc * ((sig / inv) * (sig / inv));
+          slab[oLs + o0 + d] = ((float)rows_live - sumq2) * (e * inv / sig);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  OIVAE_STAMP(3);
+  // ---- encoder backward: gradients of the pre-activations, then this workgroup's share of dW = dpre^T X ----
+  for (int o = tid; o < RB * K; o += kSmallThreads) {
+    const int r = o / K, k = o - r * K;
+    float dmu = 0.f, dsg = 0.f;
+    if (r0 + r < B) {
+      for (int s = 0; s < S; ++s) {
+        const float dzv = dzs[(s * RB + r) * KP + k];
+        dmu += dzv;
+        dsg = __builtin_fmaf(dzv, a.eps[((s * B) + r0 + r) * K + k], dsg);
+      }
+      const float mp = a.prior_mu[(r0 + r) * a.prior_stride + k], sp = a.prior_sigma[(r0 + r) * a.prior_stride + k];
+      const float sg = sgs[o];
+      dmu += ((mus[o] - mp) / (sp * sp)) * invB;
+      dsg += (sg / (sp * sp) - 1.0f / sg) * invB;
+      dsg = dsg * a.c * eas[o];
+    }
+    pre[r * 2 * K + k] = dmu;
+    pre[r * 2 * K + K + k] = dsg;
+  }
+  __syncthreads();
+  for (int o = tid; o < 2 * K * D; o += kSmallThreads) {
+    const int j = o / D, d = o - j * D;
+    float sacc = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < RB; ++r) sacc = __builtin_fmaf(pre[r * 2 * K + j], Xs[r * DP + d], sacc);
+    slab[(j < K ? oWmu + j * D : oWsig + (j - K) * D) + d] = sacc;
+  }
+  for (int j = tid; j < 2 * K; j += kSmallThreads) {
+    float sacc = 0.f;
+    for (int r = 0; r < RB; ++r) sacc += pre[r * 2 * K + j];
+    slab[(j < K ? obmu + j : obsig + (j - K))] = sacc;
+  }
+  OIVAE_STAMP(4);
+  block_sum2(kl, ll, sm);
+  if (tid == 0) { a.kl_part[blk] = kl; a.ll_part[blk] = ll; }
+  // ---- the last workgroup to arrive finishes the step ----
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_last = (atomicAdd(a.counter, 1u) == (uint32_t)(a.nblk - 1)) ? 1 : 0;
+  __syncthreads();
+  OIVAE_STAMP(5);
+  if (!s_last) return;
+  __threadfence();
+  const int nblk = a.nblk;
+  const float inv_var = 1.0f / (a.sigma_theta * a.sigma_theta);
+  double th_sq = 0.0;
+  for (int i = tid; i < P32; i += kSmallThreads) {   // gradients: the workgroups' slabs added in workgroup order
+    float sacc = 0.f;
+#pragma unroll 4
+    for (int b = 0; b < nblk; ++b) sacc += __builtin_nontemporal_load(a.slab + b * P32 + i);
+    const int q = OIVAE_SEG(i);
+    if (q == 4 || q == 5) {   // lib/oivae.py:15-23: the weight prior's value and its gradient theta / sigma^2 (mu_net weights and biases)
+      const float th = Ps[i];
+      th_sq += (double)th * (double)th;
+      sacc = __builtin_fmaf(th, inv_var, sacc);
+    }
+    a.G0[OIVAE_FOFF(q) + i - OIVAE_OFF(q)] = sacc;
+  }
+  OIVAE_STAMP(6);
+  double pen = 0.0;
+  for (int r = tid; r < G * K; r += kSmallThreads) {   // lib/models.py:113-114 on the PRE-update Ws
+    float sacc = 0.f;
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) { const float w = pWs[r * H + hh]; sacc = __builtin_fmaf(w, w, sacc); }
+    pen += (double)sqrtf(sacc);
+  }
+  double klt = 0.0, llt = 0.0;
+  if (tid == 0)
+    for (int b = 0; b < nblk; ++b) {
+      klt += __builtin_nontemporal_load(a.kl_part + b);
+      llt += __builtin_nontemporal_load(a.ll_part + b);
+    }
+  block_sum2(th_sq, pen, sm);
+  const double th_tot = th_sq, pen_tot = pen;
+  if (tid == 0) {   // as finalize_kernel (api.hip)
+    const double n_theta = (double)D * H + (double)D;
+    const double st = (double)a.sigma_theta;
+    const float lp_theta = (float)(n_theta * (-0.5 * (double)kLog2Pi - log(st)) - 0.5 * th_tot / (st * st));
+    const float z_kl = (float)klt / (float)B;
+    const float loglik = ((float)llt / (float)S) / (float)B;
+    const float penalty = (float)pen_tot;
+    const float lp_W = -a.lam * penalty;
+    const float loss = -1.0f * (-z_kl + loglik + lp_theta);
+    a.out->z_kl = z_kl; a.out->loglik_term = loglik; a.out->logprob_theta = lp_theta; a.out->logprob_W = lp_W;
+    a.out->loss = loss; a.out->elbo = -loss + lp_W; a.out->penalty = penalty; a.out->pad = 0.f;
+    *a.counter = 0;
+  }
+  OIVAE_STAMP(7);
+  if (!a.do_opt) return;
+  __syncthreads();   // this workgroup's own gradient stores, read back below
+  for (int i = tid; i < oWs; i += kSmallThreads) {   // Adam over everything before Ws
+    const int q = OIVAE_SEG(i), j = OIVAE_FOFF(q) + i - OIVAE_OFF(q);
+    float* pp = a.P0 + j;
+    float* pm = a.M0 + j;
+    float* pv = a.V0 + j;
+    float pi = *pp, mi = *pm, vi = *pv;
+    adam_update_dev(pi, a.G0[j], mi, vi, a.one_minus_b1, a.b2, a.one_minus_b2, a.step_size, a.inv_bc2_sqrt, a.adam_eps);
+    *pp = pi; *pm = mi; *pv = vi;
+  }
+  for (int r = tid; r < G * K; r += kSmallThreads)
+    prox_row_scalar_dev<true>(a.P0 + a.foff[7], a.G0 + a.foff[7], r, H, a.neg_ws_lr, a.t, a.do_prox, a.mask, a.norms, a.tab);
+  OIVAE_STAMP(8);
+}
+
+}  // namespace oivae
+
+using namespace oivae;
+
+extern "C" int oivae_small_step_applies(const oivae_shape_t* shape, int64_t B, int32_t S) {
+  if (check_shape(shape) != OIVAE_OK || B < 1 || S < 1) return 0;
+  return plan_small_step(*shape, B, S).ok ? 1 : 0;
+}
+
+extern "C" int oivae_small_step_f32(const oivae_shape_t* shape, const oivae_tensors_t* params, const oivae_tensors_t* grads,
+                                    const float* X, int64_t B, int32_t S, const float* eps, float c, float sig_off,
+                                    const float* prior_mu, const float* prior_sigma, int32_t prior_rows,
+                                    float gen_sig_off, float sigma_theta, float lam,
+                                    float* mu_q, float* sig_q, float* z, oivae_scalars_t* out,
+                                    int32_t do_optimizers, const oivae_tensors_t* adam_m, const oivae_tensors_t* adam_v,
+                                    float lr, float beta1, float beta2, float adam_eps, int32_t adam_step,
+                                    float ws_lr, float t, int32_t do_prox, uint8_t* zero_mask, float* row_norms,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+  if (int rc = check_shape(shape)) return rc;
+  if (!params || !grads || !X || !eps || !prior_mu || !prior_sigma || !mu_q || !sig_q || !z || !out || !workspace)
+    return fail(OIVAE_E_ARG, "oivae_small_step_f32: null pointer");
+  if (B < 1 || S < 1) return fail(OIVAE_E_ARG, "oivae_small_step_f32: B and S must be >= 1");
+  if (prior_rows != 1 && prior_rows != B) return fail(OIVAE_E_ARG, "oivae_small_step_f32: prior_rows must be 1 or B");
+  if (!(sigma_theta > 0.f)) return fail(OIVAE_E_ARG, "oivae_small_step_f32: sigma_theta must be > 0");
+  if (do_optimizers && (!adam_m || !adam_v || adam_step < 1))
+    return fail(OIVAE_E_ARG, "oivae_small_step_f32: the optimizers need Adam's moments and a step count >= 1");
+  const oivae_shape_t& s = *shape;
+  const SmallPlan pl = plan_small_step(s, B, S);
+  if (!pl.ok) return fail(OIVAE_E_SHAPE, "oivae_small_step_f32: shape outside the one-launch step (oivae_small_step_applies)");
+  const uint16_t* tab = rsqrt14_table_device();
+  if (!tab) return fail(OIVAE_E_NOINIT, "oivae_init has not been called on this device");
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = poll_error_word("oivae_small_step_f32", st)) return rc;
+  Workspace w;
+  if (int rc = carve_workspace(s, B, S, workspace, workspace_bytes, &w)) return rc;
+  SmallArgs a{};
+  a.D = s.D; a.K = s.K; a.G = s.G; a.H = s.H; a.DGS = s.max_group_dim; a.tanh_gen = s.gen_type == OIVAE_GEN_TANH_LINEAR;
+  a.group_off = s.group_off;
+  a.B = B; a.S = S; a.RB = pl.RB; a.NR = pl.NR; a.GR = pl.GR; a.nblk = pl.nblk;
+  {   // one layout for the four tensor sets (the engine's flat buffers have it): base pointer + eight element offsets
+    auto ptrs = [](const oivae_tensors_t& t, const float** o) {
+      o[0] = t.enc_Wmu; o[1] = t.enc_bmu; o[2] = t.enc_Wsig; o[3] = t.enc_bsig; o[4] = t.gen_W2; o[5] = t.gen_b2; o[6] = t.log_sigma; o[7] = t.Ws;
+    };
+    const float *pp[8], *gp[8], *mp[8], *vp[8];
+    ptrs(*params, pp); ptrs(*grads, gp);
+    if (do_optimizers) { ptrs(*adam_m, mp); ptrs(*adam_v, vp); }
+    for (int q = 0; q < 8; ++q) {
+      if (!pp[q] || !gp[q]) return fail(OIVAE_E_ARG, "oivae_small_step_f32: null tensor %d", q);
+      const int64_t d = pp[q] - pp[0];
+      if (d < 0 || d > 0x3fffffff || gp[q] - gp[0] != d ||
+          (do_optimizers && q < 7 && (!mp[q] || !vp[q] || mp[q] - mp[0] != d || vp[q] - vp[0] != d)))
+        return fail(OIVAE_E_ARG, "oivae_small_step_f32: params, grads and Adam's moments must share one layout (tensor %d "
+                                 "at another offset from enc_Wmu)", q);
+      a.foff[q] = (int)d;
+    }
+    a.P0 = const_cast<float*>(pp[0]); a.G0 = const_cast<float*>(gp[0]);
+    a.M0 = do_optimizers ? const_cast<float*>(mp[0]) : nullptr; a.V0 = do_optimizers ? const_cast<float*>(vp[0]) : nullptr;
+  }
+  a.X = X; a.eps = eps; a.c = c; a.sig_off = sig_off; a.gen_sig_off = gen_sig_off;
+  a.prior_mu = prior_mu; a.prior_sigma = prior_sigma; a.prior_stride = prior_rows == 1 ? 0 : s.K;
+  a.mu_q = mu_q; a.sig_q = sig_q; a.z = z;
+  a.sigma_theta = sigma_theta; a.lam = lam; a.out = out;
+  a.do_opt = do_optimizers ? 1 : 0;
+  {   // scalar prep in double like torch's _single_tensor_adam (and oivae_adam_f32)
+    const double bc1 = 1.0 - pow((double)beta1, (double)(adam_step < 1 ? 1 : adam_step));
+    const double bc2 = 1.0 - pow((double)beta2, (double)(adam_step < 1 ? 1 : adam_step));
+    a.step_size = (float)((double)lr / bc1);
+    a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    a.one_minus_b1 = 1.0f - beta1; a.b2 = beta2; a.one_minus_b2 = 1.0f - beta2; a.adam_eps = adam_eps;
+  }
+  a.neg_ws_lr = -ws_lr; a.t = t; a.do_prox = do_prox ? 1 : 0;
+  a.mask = zero_mask; a.norms = row_norms; a.tab = tab;
+  char* base = w.small;
+  a.slab = reinterpret_cast<float*>(base);
+  a.P = pl.P;
+  base += align_up((int64_t)sizeof(float) * pl.P * pl.nblk, 256);
+  a.kl_part = reinterpret_cast<double*>(base);
+  base += align_up((int64_t)sizeof(double) * pl.nblk, 256);
+  a.ll_part = reinterpret_cast<double*>(base);
+  base += align_up((int64_t)sizeof(double) * pl.nblk, 256);
+  a.counter = reinterpret_cast<uint32_t*>(base);
+  a.stamps = reinterpret_cast<unsigned long long*>(base + 64);   // (scratch builds with OIVAE_SMALL_STAMPS: 16 stamps per workgroup)
+  int64_t off = 0;
+  a.oWmu = off; off += (int64_t)s.K * s.D;
+  a.obmu = off; off += s.K;
+  a.oWsig = off; off += (int64_t)s.K * s.D;
+  a.obsig = off; off += s.K;
+  a.oW2 = off; off += (int64_t)s.D * s.H;
+  a.ob2 = off; off += s.D;
+  a.oLs = off; off += s.D;
+  a.oWs = off; off += (int64_t)s.G * s.K * s.H;
+  OIVAE_HIP_CHECK(hipMemsetAsync(a.counter, 0, 4, st));   // (a workspace may hold anything; the kernel lowers it again itself)
+#define OIVAE_SMALL_LAUNCH(HH)                                                                                    \
+  {                                                                                                               \
+    OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_step_kernel<HH>),                     \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));          \
+    hipLaunchKernelGGL(small_step_kernel<HH>, dim3((unsigned)pl.nblk), dim3(kSmallThreads), pl.lds_bytes, st, a); \
+  }
+  if (s.H == 1) OIVAE_SMALL_LAUNCH(1)
+  else if (s.H == 2) OIVAE_SMALL_LAUNCH(2)
+  else if (s.H == 4) OIVAE_SMALL_LAUNCH(4)
+  else OIVAE_SMALL_LAUNCH(8)
+#undef OIVAE_SMALL_LAUNCH
+  OIVAE_LAUNCH_CHECK();
+  return OIVAE_OK;
+}

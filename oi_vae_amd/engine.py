@@ -118,6 +118,7 @@ class Engine:
     self.bound = []  # (user tensor, grad view) pairs set by adopt()
     self._eval_grads = None
     self._eval_gt = None
+    self._adam_mt = None   # (adam_m it was built for, Tensors of the moments' views) for small_step
 
   def _timed(self, name, fn):
     if self.trace is None or (self.trace_names is not None and name not in self.trace_names):
@@ -325,6 +326,54 @@ class Engine:
     this is the definite answer, e.g. behind the last step of a run."""
     with torch.cuda.device(self.device):
       _lib.check(self.lib.oivae_check_errors(self._stream()), "oivae_check_errors")
+
+  def small_step_applies(self, B, S) -> bool:
+    """Whether the one-launch step (oivae_small_step_f32: the scripts' own small shapes) takes this model and batch."""
+    return bool(self.lib.oivae_small_step_applies(ctypes.byref(self._shape), int(B), int(S)))
+
+  def small_step(self, X, eps, c, prox_step_size, lr, Ws_lr, betas=(0.9, 0.999), adam_eps=1e-8, do_prox=True,
+                 optimizers=True, sig_off=1e-3, gen_sig_off=1e-3, prior_mu=None, prior_sigma=None, sigma_theta=1.0, lam=1.0):
+    """The whole step in one launch (include/oivae_hip.h oivae_small_step_f32): forward, backward, scalars and -- with
+    `optimizers` -- Adam, SGD on Ws and the proximal step.  Returns what forward_backward returns (pre-update values)."""
+    s = self.spec
+    with torch.cuda.device(self.device):
+      X = self._dev_f32(X, "X")
+      eps = self._dev_f32(eps, "eps")
+      B, S = X.size(0), eps.size(0)
+      if X.dim() != 2 or X.size(1) != s.D or eps.dim() != 3 or eps.size(1) != B or eps.size(2) != s.K:
+        raise ValueError("X must be [B, %d] and eps [S, B, %d]" % (s.D, s.K))
+      if prior_mu is None:
+        prior_mu, prior_sigma = self._const("prior0", 0.0), self._const("prior1", 1.0)
+      prior_mu = self._dev_f32(prior_mu, "prior_mu").view(-1, s.K)
+      prior_sigma = self._dev_f32(prior_sigma, "prior_sigma").view(-1, s.K)
+      prior_rows = prior_mu.size(0)
+      if prior_rows not in (1, B) or prior_sigma.size(0) != prior_rows:
+        raise ValueError("prior_z must have 1 or B=%d rows, got %d" % (B, prior_rows))
+      ws = self._workspace(B, S)
+      mu_q = torch.empty(B, s.K, dtype=torch.float32, device=self.device)
+      sig_q = torch.empty(B, s.K, dtype=torch.float32, device=self.device)
+      z = torch.empty(B * S, s.K, dtype=torch.float32, device=self.device)
+      if optimizers:
+        if self.adam_m is None:
+          self.adam_m = torch.zeros(self.adam_numel, dtype=torch.float32, device=self.device)
+          self.adam_v = torch.zeros(self.adam_numel, dtype=torch.float32, device=self.device)
+        if self._adam_mt is None or self._adam_mt[0] is not self.adam_m:
+          shapes = s.seg_shapes()
+          def tens(flat):
+            return self._tensors({n: (self._view(flat, n, shapes[n]) if n != "Ws" else flat[0:0]) for n in _SEG_ORDER})
+          self._adam_mt = (self.adam_m, tens(self.adam_m), tens(self.adam_v))
+        self.adam_t += 1
+        am, av = ctypes.byref(self._adam_mt[1]), ctypes.byref(self._adam_mt[2])
+      else:
+        am = av = None
+      _lib.check(self._timed("small_step", lambda: self.lib.oivae_small_step_f32(
+        ctypes.byref(self._shape), ctypes.byref(self._pt), ctypes.byref(self._gt), X.data_ptr(), B, S, eps.data_ptr(),
+        float(c), float(sig_off), prior_mu.data_ptr(), prior_sigma.data_ptr(), prior_rows, float(gen_sig_off),
+        float(sigma_theta), float(lam), mu_q.data_ptr(), sig_q.data_ptr(), z.data_ptr(), self.scalars.data_ptr(),
+        1 if optimizers else 0, am, av, float(lr), float(betas[0]), float(betas[1]), float(adam_eps), max(self.adam_t, 1),
+        float(Ws_lr), float(prox_step_size), 1 if do_prox else 0, self.zero_mask.data_ptr(), self.row_norms.data_ptr(),
+        ws.data_ptr(), self._ws_bytes, self._stream())), "oivae_small_step_f32")
+    return dict(mu_q=mu_q, sig_q=sig_q, z=z, scalars=self.scalars, X=X, eps=eps)
 
   def _const(self, name, val):
     t = self._bufs.get(name)

@@ -105,6 +105,8 @@ class OIVAE(object):
       for t, gv in pairs:
         t.grad = gv                # ... and the views are bound again
     dp = self.data_parallel and parallel.is_active(self.process_group)
+    if not dp and eng.small_step_applies(B, len(eps)):
+      return self._small_step(X, eps, c, sig_off, pm, ps, prox_step_size)
     sync = parallel.BucketedGradSync(eng, self.process_group) if dp else None
     out = eng.forward_backward(X.detach() if torch.is_tensor(X) else X, eps, c, sig_off=sig_off,
                                gen_sig_off=eng.gen_sig_off, prior_mu=pm, prior_sigma=ps,
@@ -127,6 +129,31 @@ class OIVAE(object):
     if dp:
       sync.wait()
       parallel.reduce_scalars_(scalars, self.process_group)
+    for opt in self.optimizers:
+      opt.step()
+    if fuse:
+      eng.sgd_prox_step(self._fused_sgd._lr(), prox_step_size, do_prox=True)
+    elif self.lam > 0:
+      self.generative_model.proximal_step(prox_step_size)
+    return self._info(out, scalars)
+
+  def _small_step(self, X, eps, c, sig_off, pm, ps, prox_step_size):
+    """The scripts' own small models (bars, mocap) on one GPU: the whole step is ONE launch (csrc/small_step.hip) --
+    with the engine's optimizers inside it, with caller-owned torch.optim instances behind it."""
+    eng = self.engine
+    common = dict(sig_off=sig_off, gen_sig_off=eng.gen_sig_off, prior_mu=pm, prior_sigma=ps,
+                  sigma_theta=float(self.prior_theta.sigma), lam=float(self.lam))
+    Xd = X.detach() if torch.is_tensor(X) else X
+    if self._all_native:
+      a = self._fused_adam
+      out = eng.small_step(Xd, eps, c, prox_step_size, lr=a._lr(), Ws_lr=self._fused_sgd._lr(), betas=a._uniform("betas"),
+                           adam_eps=a._uniform("eps"), do_prox=self.lam > 0, optimizers=True, **common)
+      return self._info(out, out["scalars"].clone())
+    out = eng.small_step(Xd, eps, c, prox_step_size, lr=0.0, Ws_lr=0.0, optimizers=False, **common)
+    scalars = out["scalars"].clone()
+    fuse = self._fused_sgd is not None and self.lam > 0
+    if self._fused_sgd is not None:
+      self._fused_sgd.fused_with_prox = fuse
     for opt in self.optimizers:
       opt.step()
     if fuse:
