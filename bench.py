@@ -34,7 +34,8 @@ F16_MATRIX_SUSTAINED_TFLOPS = 2006.0
 PMC_FILE = os.path.join("profiles", "pmc_per_kernel_latest.json")
 
 
-DEC_SOURCES = ("oi_vae_amd/csrc/dec_x3_64s.h", "oi_vae_amd/csrc/mfma_decoder.hip", "oi_vae_amd/csrc/x3_split.h")
+DEC_SOURCES = ("oi_vae_amd/csrc/dec_x3_64s.h", "oi_vae_amd/csrc/mfma_decoder.hip", "oi_vae_amd/csrc/dec_shared.h",
+               "oi_vae_amd/csrc/x3_split.h")
 
 
 def decoder_source_digest():

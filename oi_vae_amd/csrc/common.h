@@ -31,7 +31,7 @@ inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 // Device pointer to the 65536-entry rsqrt14 table of the current device
 // (uploaded by oivae_init), or nullptr.
 const uint16_t* rsqrt14_table_device();
-// The current device's error words, raised together by a kernel whose bounded wait runs out (mfma_decoder.hip
+// The current device's error words, raised together by a kernel whose bounded wait runs out (dec_shared.h
 // lds_wait_ge): `host` is one word of host-mapped memory the library polls, `dev` its device-resident twin (behind the
 // rsqrt14 table, the allocation every proximal kernel already holds a pointer to) that the UPDATE kernels -- Adam,
 // SGD, the proximal step -- read first: with it raised they return without touching a parameter, so gradients of a

@@ -1,5 +1,5 @@
-// dec_x3_64s: dec_x3_64g (mfma_decoder.hip) on v_mfma_f32_16x16x32_f16.  Included by mfma_decoder.hip, inside
-// namespace oivae, behind dec_x3_64g, whose arguments, LDS plan, set-up, hand-over protocol and end of kernel it shares.
+// dec_x3_64s: dec_x3_64g (xcheck_decoders.hip) on v_mfma_f32_16x16x32_f16.  Included by mfma_decoder.hip, inside
+// namespace oivae; dec_x3_64g's arguments, LDS plan, set-up, hand-over protocol and end of kernel are shared (dec_shared.h).
 //
 // Why another instruction shape: the chip is power-limited under these kernels, and per flop the 16x16x32 instruction
 // draws less than 32x32x16 (tools/probe/mfma_shape_power.hip: 2006 against 1772 TFLOP/s on random operands).  A timing

@@ -1,5 +1,5 @@
 """The role-split decoder kernels hand tiles between waves through LDS counters and wait for them with a bound
-(csrc/mfma_decoder.hip lds_wait_ge).  A wait that runs out must not pass silently (round 1: the wave went on and read an
+(csrc/dec_shared.h lds_wait_ge).  A wait that runs out must not pass silently (round 1: the wave went on and read an
 unpublished tile, rc == 0): the wave raises the library's error word in host-mapped memory and the NEXT step entry point
 on that device fails with OIVAE_E_HIP.  liboivae_hip_waittest.so is the library with the bound set to one poll
 (-DOIVAE_TEST_WAIT_LIMIT=1, csrc/Makefile), so that every hand-over that is not already complete times out; the kernel
