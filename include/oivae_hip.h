@@ -139,6 +139,18 @@ int oivae_sgd_prox_f32(float* Ws, const float* dWs, int64_t rows, int32_t H,
 int oivae_prox_cols_f32(float* W, const int32_t* group_off, int32_t G, int32_t K, int32_t max_group_rows,
                         float t, uint8_t* zero_mask, float* col_norms, void* stream);
 
+/* Gamma log-likelihood: replaces Gamma.logprob, lib/distributions.py:65-71 -- the sum over n elements of
+ *   shape*log(rate) - lgamma(shape) + (shape-1)*log(x) - rate*x
+ * (each element's four terms added in fp32 in that order, so 0*log 0 = NaN as in the reference; the sum over elements
+ * in fp64, fixed order) -- and, for every non-NULL gradient pointer (n floats each), what autograd derives from it:
+ * d_shape = log(rate) - digamma(shape) + log(x), d_rate = shape/rate - x, d_x = (shape-1)/x - rate.  logprob: one float
+ * on the device.  workspace: oivae_gamma_workspace_bytes() bytes of device memory, 8-byte aligned.  Evaluation-side
+ * operator: the reference's training step cannot take Gamma members (lib/distributions.py:82 asks them for `size`). */
+int64_t oivae_gamma_workspace_bytes(void);
+int oivae_gamma_logprob_f32(const float* shape, const float* rate, const float* x, int64_t n, float* logprob,
+                            float* d_shape, float* d_rate, float* d_x, void* workspace, int64_t workspace_bytes,
+                            void* stream);
+
 /* ---- encoder forward + reparameterisation + KL ---------------------------
  * Replaces inference_model(X) (lib/models.py:15-16 with the heads of
  * bars_data_oivae.py:66-87), KL_Normals (lib/utils.py:9-18, lib/oivae.py:50)

@@ -24,6 +24,7 @@ SYMBOLS = [
   "oivae_decoder_fwd_bwd_f32", "oivae_encoder_bwd_f32", "oivae_finalize_f32",
   "oivae_adam_f32", "oivae_encoder_bwd_noalloc_f32", "oivae_dz_layout", "oivae_reload_test_hooks",
   "oivae_check_errors", "oivae_small_step_applies", "oivae_small_step_f32",
+  "oivae_gamma_workspace_bytes", "oivae_gamma_logprob_f32",
 ]
 
 
@@ -90,6 +91,10 @@ def bind(path):
   L.oivae_small_step_f32.restype = ctypes.c_int
   L.oivae_check_errors.argtypes = [c_vp]
   L.oivae_check_errors.restype = ctypes.c_int
+  L.oivae_gamma_workspace_bytes.argtypes = []
+  L.oivae_gamma_workspace_bytes.restype = c_i64
+  L.oivae_gamma_logprob_f32.argtypes = [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]
+  L.oivae_gamma_logprob_f32.restype = ctypes.c_int
   L.oivae_reload_test_hooks.argtypes = []
   L.oivae_reload_test_hooks.restype = None
   for name in ("oivae_prox_f32", "oivae_sgd_prox_f32", "oivae_prox_cols_f32", "oivae_encoder_fwd_f32", "oivae_decoder_fwd_bwd_f32",

@@ -76,16 +76,16 @@ __global__ __launch_bounds__(kGammaThreads) void gamma_logprob_final(const doubl
 
 using namespace oivae;
 
-extern "C" size_t oivae_gamma_workspace_bytes(void) { return sizeof(double) * kGammaMaxBlocks; }
+extern "C" int64_t oivae_gamma_workspace_bytes(void) { return (int64_t)sizeof(double) * kGammaMaxBlocks; }
 
 extern "C" int oivae_gamma_logprob_f32(const float* shape, const float* rate, const float* x, int64_t n, float* logprob,
-                                       float* d_shape, float* d_rate, float* d_x, void* workspace, size_t workspace_bytes,
+                                       float* d_shape, float* d_rate, float* d_x, void* workspace, int64_t workspace_bytes,
                                        void* stream) {
   if (!logprob || n < 0 || (n > 0 && (!shape || !rate || !x)))
     return fail(OIVAE_E_ARG, "oivae_gamma_logprob_f32: null pointer or negative size");
   if (!workspace || workspace_bytes < oivae_gamma_workspace_bytes() || (reinterpret_cast<uintptr_t>(workspace) & 7))
-    return fail(OIVAE_E_WORKSPACE, "oivae_gamma_logprob_f32: workspace of %zu bytes (8-byte aligned) needed",
-                oivae_gamma_workspace_bytes());
+    return fail(OIVAE_E_WORKSPACE, "oivae_gamma_logprob_f32: workspace of %lld bytes (8-byte aligned) needed",
+                (long long)oivae_gamma_workspace_bytes());
   hipStream_t st = (hipStream_t)stream;
   if (int rc = poll_error_word("oivae_gamma_logprob_f32", st)) return rc;
   int64_t blocks = (n + kGammaThreads * 4 - 1) / (kGammaThreads * 4);   // about four elements per thread

@@ -41,6 +41,36 @@ class Normal(object):
     return Normal(self.mu.expand(size), self.sigma.expand(size))
 
 
+class _GammaLogProb(torch.autograd.Function):
+  """Gamma.logprob on device tensors through oivae_gamma_logprob_f32: the log-likelihood and the gradients autograd
+  would derive from the reference's expression (lib/distributions.py:65-71), inputs read once.  No CPU route: host
+  tensors take the torch expression in Gamma.logprob."""
+
+  @staticmethod
+  def forward(ctx, shape, rate, x):
+    import ctypes
+
+    from . import _lib
+    L = _lib.init_device(shape.device.index)
+    a, b, v = shape.contiguous(), rate.contiguous(), x.contiguous()
+    need = [ctx.needs_input_grad[i] for i in range(3)]
+    grads = [torch.empty_like(a) if n else None for n in need]
+    out = torch.empty(1, device=a.device, dtype=torch.float32)
+    ws_bytes = int(L.oivae_gamma_workspace_bytes())
+    ws = torch.empty(ws_bytes // 8, device=a.device, dtype=torch.float64)
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    with torch.cuda.device(a.device):
+      rc = L.oivae_gamma_logprob_f32(ptr(a), ptr(b), ptr(v), a.numel(), ptr(out), ptr(grads[0]), ptr(grads[1]), ptr(grads[2]),
+                                     ptr(ws), ws_bytes, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "oivae_gamma_logprob_f32")
+    ctx.grads = grads
+    return out[0]
+
+  @staticmethod
+  def backward(ctx, g):
+    return tuple(None if d is None else d * g for d in ctx.grads)
+
+
 class Gamma(object):
   """Gamma(shape, rate) observation model for non-negative data (counterpart of
   lib/distributions.py:59-71, which has `logprob` only).  `size` and `sample` are additions: without
@@ -67,6 +97,8 @@ class Gamma(object):
     added in that order (lib/distributions.py:65-70): the same bits as the reference, and its NaN at x = 0 with
     shape 1 (0 * log 0), which torch.distributions' xlogy would turn into 0."""
     a, b = self.shape, self.rate
+    if x.is_cuda and a.is_cuda and b.is_cuda and a.dtype == b.dtype == x.dtype == torch.float32 and a.shape == x.shape:
+      return _GammaLogProb.apply(a, b, x)   # one pass over the data on the GPU (csrc/gamma.hip), forward and gradients
     return torch.sum(a * torch.log(b) - torch.lgamma(a) + (a - 1) * torch.log(x) - b * x)
 
 

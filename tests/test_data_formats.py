@@ -140,3 +140,22 @@ def test_distribution_classes_match_reference_vectors():
   assert isinstance(mixed, _DistributionCat)
   xm = torch.cat([x[:, :4], t("gamma_x")], dim=1)
   assert abs(mixed.logprob(xm).item() - (parts[0].logprob(x[:, :4]).item() + got)) < 1e-3
+
+
+def test_gamma_host_expression_matches_the_reference_in_every_regime():
+  """Gamma.logprob on host tensors (the torch expression in the reference's term order) against the values recorded
+  from the reference's class in four regimes (tests/golden/make_golden_gamma.py); on this torch build: the same bits."""
+  import torch
+  from oi_vae_amd.distributions import Gamma
+  z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gamma_vectors.npz"))
+  for name in ("typical", "small_shape", "large_shape", "one"):
+    a, b, x = (torch.tensor(z[name + "/" + k], requires_grad=True) for k in ("shape", "rate", "x"))
+    lp = Gamma(a, b).logprob(x)
+    ref = float(z[name + "/logprob"])
+    assert abs(lp.item() - ref) <= 1e-6 * abs(ref), name
+    lp.backward()
+    for k, t in (("d_shape", a), ("d_rate", b), ("d_x", x)):
+      r = z[name + "/" + k]
+      assert np.abs(t.grad.numpy() - r).max() <= 1e-5 * np.abs(r).max(), (name, k)
+  a, b, x = (torch.tensor(z["zero_x/" + k]) for k in ("shape", "rate", "x"))
+  assert torch.isnan(Gamma(a, b).logprob(x)).item() and np.isnan(float(z["zero_x/logprob"]))
