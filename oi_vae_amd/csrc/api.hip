@@ -109,7 +109,7 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
   w->n_ll = plan.flat ? flat_decoder_blocks(s) : s.G * plan.chunks;
   w->ll_part = reinterpret_cast<double*>(take(sizeof(double) * kMaxPartials));
   w->n_bias = enc_bias_blocks(B);  // at least 16 rows per block
-  w->bias_part = reinterpret_cast<double*>(take(sizeof(double) * kBiasBlocks * 2 * s.K));
+  w->bias_part = reinterpret_cast<double*>(take(enc_bias_part_bytes(kBiasBlocks, s.K)));
   w->n_theta = 2048;  // 512 blocks per generator parameter array; every slot written each step
   w->theta_part = reinterpret_cast<double*>(take(sizeof(double) * 2048));
   {

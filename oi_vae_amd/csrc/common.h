@@ -71,6 +71,9 @@ struct Workspace {
 
 constexpr int kMaxPartials = 16384;
 constexpr int kEncEpiBlocks = 2048;  // cap on enc_fwd_epilogue blocks (= KL partials)
+// bytes of the encoder backward's per-block partials: [n_bias, 2K] column sums of dpre (doubles) and, behind them,
+// [n_bias, 2K] column maxima of |dpre| (bit patterns) for the fp16 backward GEMM's per-column scales
+inline int64_t enc_bias_part_bytes(int n_bias, int K) { return (int64_t)(sizeof(double) + sizeof(uint32_t)) * n_bias * 2 * K; }
 constexpr int kBiasBlocks = 1024;    // cap on enc_bwd_pre blocks (= bias-gradient partials)
 constexpr int kMaxEncSplits = 8;     // split-K partial images of the encoder pre-activations  // cap on per-kernel block counts that emit partials
 
@@ -144,7 +147,7 @@ int64_t x3_encoder_bwd_img_bytes(const oivae_shape_t& s, int64_t B);  // image o
 int x3_encoder_fwd_splits(const oivae_shape_t& s, int64_t B);
 bool x3_encoder_bwd_applies(const oivae_shape_t& s, int64_t B);
 int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X, const float* dpre,
-                          int64_t B, uint32_t* img, uint32_t* rng, hipStream_t st);
+                          int64_t B, uint32_t* img, uint32_t* rng, hipStream_t st, bool colmax_ready = false);
 int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params, const float* X, int64_t B,
                           float* pre, uint32_t* wimg, uint32_t* rng, int splits, hipStream_t st,
                           bool image_ready = false);   // image_ready: wimg and rng[1] (max|W|) were prepared by the caller

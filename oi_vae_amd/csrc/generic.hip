@@ -582,11 +582,15 @@ __global__ __launch_bounds__(256) void enc_bwd_pre(int64_t B, int K, int S, cons
                                                    const float* __restrict__ mu_q,
                                                    const float* __restrict__ sig_q,
                                                    const float* __restrict__ ea, float* __restrict__ dpre,
-                                                   double* __restrict__ bias_part) {
+                                                   double* __restrict__ bias_part, uint32_t* __restrict__ max_part) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* col = reinterpret_cast<double*>(smem_raw);  // [2K] column sums of this block
   const int tid = threadIdx.x;
-  for (int j = tid; j < 2 * K; j += 256) col[j] = 0.0;
+  // max_part (the fp16 backward GEMM follows): this block's max|dpre[:, j]| per column, as bit patterns -- the scales
+  // of the dpre^T image are per column (x3_encoder.hip h2_split_cols); found here, where dpre is made, instead of by a
+  // pass of its own over dpre (20 us at 8192 rows)
+  uint32_t* cmax = reinterpret_cast<uint32_t*>(col + 2 * K + 512) + ((dz_sn == 1 && S == 1) ? 65 * K : 0);   // [2K]
+  for (int j = tid; j < 2 * K; j += 256) { col[j] = 0.0; if (max_part) cmax[j] = 0u; }
   __syncthreads();
   const int64_t rpb = (B + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
@@ -594,6 +598,7 @@ __global__ __launch_bounds__(256) void enc_bwd_pre(int64_t B, int K, int S, cons
   const float invB = 1.0f / (float)B;
   const bool fixed_col = (256 % K) == 0;  // then thread t always meets column t % K: sums stay in registers
   double smu = 0.0, sda = 0.0;
+  float mmu = 0.f, mda = 0.f;
   auto element = [&](int64_t i, int64_t b, int k, float sdz, float sdze) {
     const float mp = prior_mu[b * prior_stride + k], sp = prior_sigma[b * prior_stride + k];
     const float sq = sig_q[i];
@@ -602,8 +607,11 @@ __global__ __launch_bounds__(256) void enc_bwd_pre(int64_t B, int K, int S, cons
     const float da = dsig * c * ea[i];
     dpre[b * 2 * K + k] = dmu;
     dpre[b * 2 * K + K + k] = da;
-    if (fixed_col) { smu += (double)dmu; sda += (double)da; }
-    else { atomicAdd(&col[k], (double)dmu); atomicAdd(&col[K + k], (double)da); }  // LDS; odd K only (order-dependent in the last bits)
+    if (fixed_col) { smu += (double)dmu; sda += (double)da; mmu = fmaxf(mmu, fabsf(dmu)); mda = fmaxf(mda, fabsf(da)); }
+    else {
+      atomicAdd(&col[k], (double)dmu); atomicAdd(&col[K + k], (double)da);  // LDS; odd K only (order-dependent in the last bits)
+      if (max_part) { atomicMax(&cmax[k], __float_as_uint(fabsf(dmu))); atomicMax(&cmax[K + k], __float_as_uint(fabsf(da))); }
+    }
   };
   if (dz_sn == 1 && S == 1) {
     // dz arrives transposed ([K, N], the matrix-core decoders): consecutive threads of the element loop below meet
@@ -651,30 +659,49 @@ __global__ __launch_bounds__(256) void enc_bwd_pre(int64_t B, int K, int S, cons
       col[tid] = a;
       col[K + tid] = d;
     }
+    if (max_part) {   // a maximum does not care for the order (NaN: fmaxf drops it here as absmax_cols_f32 did)
+      atomicMax(&cmax[tid % K], __float_as_uint(mmu));
+      atomicMax(&cmax[K + tid % K], __float_as_uint(mda));
+    }
   }
   __syncthreads();
-  for (int j = tid; j < 2 * K; j += 256) bias_part[(int64_t)blockIdx.x * 2 * K + j] = col[j];
+  for (int j = tid; j < 2 * K; j += 256) {
+    bias_part[(int64_t)blockIdx.x * 2 * K + j] = col[j];
+    if (max_part) max_part[(int64_t)blockIdx.x * 2 * K + j] = cmax[j];
+  }
 }
 
 // one block per column j: the per-block partials are folded by a fixed-shape tree (deterministic)
 __global__ __launch_bounds__(256) void enc_bwd_bias_final(const double* __restrict__ bias_part, int nblk, int K,
                                                           float* __restrict__ dbmu, float* __restrict__ dbsig,
-                                                          uint32_t* __restrict__ rng, uint32_t* __restrict__ colmax) {
+                                                          uint32_t* __restrict__ rng, uint32_t* __restrict__ colmax,
+                                                          const uint32_t* __restrict__ max_part) {
   __shared__ double sm[256];
+  __shared__ uint32_t mx[256];
   const int j = blockIdx.x;
   // the ranges the fp16 backward GEMM's helpers accumulate into with atomicMax start at zero (x3_encoder.hip:
   // [2] max|dpre|, [8] max|x| the kernel reads, [9] its redo flag); done here, one kernel ahead of them, instead of
   // two memsets of their own
   if (rng != nullptr && j == 0 && threadIdx.x == 0) { rng[2] = 0u; rng[8] = 0u; rng[9] = 0u; }
-  if (colmax != nullptr && threadIdx.x == 0) colmax[j] = 0u;   // ... and the per-column maxima of dpre (one block per column)
+  // ... and column j's maximum of |dpre| over the blocks' partial maxima (bit patterns of non-negative floats order
+  // like the floats)
   double acc = 0.0;
-  for (int b = threadIdx.x; b < nblk; b += 256) acc += bias_part[(int64_t)b * 2 * K + j];
+  uint32_t m = 0u;
+  for (int b = threadIdx.x; b < nblk; b += 256) {
+    acc += bias_part[(int64_t)b * 2 * K + j];
+    if (max_part != nullptr) { const uint32_t v = max_part[(int64_t)b * 2 * K + j]; m = v > m ? v : m; }
+  }
   sm[threadIdx.x] = acc;
+  mx[threadIdx.x] = m;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+    if ((int)threadIdx.x < s) {
+      sm[threadIdx.x] += sm[threadIdx.x + s];
+      mx[threadIdx.x] = mx[threadIdx.x + s] > mx[threadIdx.x] ? mx[threadIdx.x + s] : mx[threadIdx.x];
+    }
     __syncthreads();
   }
+  if (colmax != nullptr && threadIdx.x == 0) colmax[j] = mx[0];
   if (threadIdx.x == 0) {
     if (j < K) dbmu[j] = (float)sm[0]; else dbsig[j - K] = (float)sm[0];
   }
@@ -944,16 +971,20 @@ int oivae::encoder_bwd_run(const oivae_shape_t& s, const oivae_tensors_t* grads,
                            double* bias_part, int n_bias, uint32_t* x3_img, uint32_t* rng, float* bwd_part, hipStream_t st) {
   const bool dz_transposed = plan_decoder(s, B * (int64_t)S).mfma;
   const int64_t dz_sn = dz_transposed ? 1 : s.K, dz_sk = dz_transposed ? B * (int64_t)S : 1;
-  const size_t pre_lds = sizeof(double) * (2 * (size_t)s.K + 512) + ((dz_sn == 1 && S == 1) ? sizeof(float) * 65 * (size_t)s.K : 0);
+  const bool h2 = x3_encoder_bwd_applies(s, B);
+  const size_t pre_lds = sizeof(double) * (2 * (size_t)s.K + 512) + ((dz_sn == 1 && S == 1) ? sizeof(float) * 65 * (size_t)s.K : 0) +
+                         sizeof(uint32_t) * 2 * (size_t)s.K;
+  // the blocks' column maxima of |dpre| sit behind their column sums (enc_bias_part_bytes)
+  uint32_t* max_part = h2 ? reinterpret_cast<uint32_t*>(bias_part + (int64_t)n_bias * 2 * s.K) : (uint32_t*)nullptr;
   hipLaunchKernelGGL(enc_bwd_pre, dim3((unsigned)n_bias), dim3(256), pre_lds, st, B, s.K, S, dz, dz_sn, dz_sk, eps, c,
-                     prior_mu, prior_sigma, prior_rows == 1 ? 0 : s.K, mu_q, sig_q, ea, dpre, bias_part);
+                     prior_mu, prior_sigma, prior_rows == 1 ? 0 : s.K, mu_q, sig_q, ea, dpre, bias_part, max_part);
   OIVAE_LAUNCH_CHECK();
   hipLaunchKernelGGL(enc_bwd_bias_final, dim3((unsigned)(2 * s.K)), dim3(256), 0, st, bias_part, n_bias,
                      s.K, grads->enc_bmu, grads->enc_bsig, rng,
-                     x3_encoder_bwd_applies(s, B) ? h2_bwd_colmax(x3_img, 2 * s.K, B) : (uint32_t*)nullptr);
+                     h2 ? h2_bwd_colmax(x3_img, 2 * s.K, B) : (uint32_t*)nullptr, (const uint32_t*)max_part);
   OIVAE_LAUNCH_CHECK();
-  if (x3_encoder_bwd_applies(s, B)) {
-    if (int rc = launch_encoder_bwd_x3(s, grads, X, dpre, B, x3_img, rng, st)) return rc;
+  if (h2) {
+    if (int rc = launch_encoder_bwd_x3(s, grads, X, dpre, B, x3_img, rng, st, /*colmax_ready=*/true)) return rc;
   } else if (mfma_encoder_applies(s)) {
     if (int rc = launch_encoder_bwd_mfma(s, grads, X, dpre, B, bwd_part, st)) return rc;
   } else {

@@ -51,7 +51,7 @@ extern "C" int oivae_encoder_bwd_noalloc_f32(const oivae_shape_t* shape, const o
   // carve: dpre | bias partials | image of dpre^T | partial images of the fp32 backward GEMM | ranges
   const int n_bias = enc_bias_blocks(B);
   const int64_t b_dpre = align_up((int64_t)sizeof(float) * B * 2 * s.K, 256);
-  const int64_t b_bias = align_up((int64_t)sizeof(double) * n_bias * 2 * s.K, 256);
+  const int64_t b_bias = align_up(enc_bias_part_bytes(n_bias, s.K), 256);
   const int64_t b_img = align_up(x3_encoder_bwd_img_bytes(s, B), 256);
   const int64_t b_part = align_up(enc_bwd_part_bytes(s, B, x3_encoder_bwd_applies(s, B)), 256);
   const int64_t need = b_dpre + b_bias + b_img + b_part + 256;

@@ -983,17 +983,18 @@ int launch_encoder_fwd_x3(const oivae_shape_t& s, const oivae_tensors_t* params,
 }
 
 int launch_encoder_bwd_x3(const oivae_shape_t& s, const oivae_tensors_t* grads, const float* X, const float* dpre,
-                          int64_t B, uint32_t* img, uint32_t* rng, hipStream_t st) {
+                          int64_t B, uint32_t* img, uint32_t* rng, hipStream_t st, bool colmax_ready) {
   if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(img) & 15))
     return fail(OIVAE_E_ARG, "x3 encoder: X and the workspace must be 16-byte aligned");
   const int J = 2 * s.K, Jp = x3_rows_pad(J);
   const int BT = (int)((B + 31) / 32);
   const int64_t chunks = (int64_t)Jp * BT * 4;
   if (h2_enabled()) {
-    // rng[8], rng[9] and the Jp column maxima behind the image were zeroed by the caller (generic.hip: encoder_bwd_run
-    // has enc_bwd_bias_final, the kernel before this one, do it; flat_decoder.hip uses memsets)
+    // rng[8], rng[9] were zeroed by the caller, and the Jp column maxima of dpre behind the image either hold their
+    // values already (colmax_ready: generic.hip encoder_bwd_run finds them where dpre is made, enc_bwd_pre +
+    // enc_bwd_bias_final) or were zeroed for the pass over dpre below (flat_decoder.hip: memsets)
     uint32_t* colmax = h2_bwd_colmax(img, J, B);
-    {
+    if (!colmax_ready) {
       int64_t nb = (B + 15) / 16;   // a chain of dependent loads per lane: short chains, many workgroups
       if (nb > 512) nb = 512;
       hipLaunchKernelGGL(absmax_cols_f32, dim3((unsigned)nb), dim3(256), 0, st, dpre, B, J, colmax);
