@@ -22,7 +22,10 @@ CONFIGS = {
   "wide-prox (G=8192x4, K=256, H=8, B=1024)": dict(dims=[4] * 8192, K=256, H=8, typ="linear", M=0, B=1024, S=1),
 }
 dev = torch.device("cuda", 0)
+only = sys.argv[1:]   # substrings of configuration names; none = all
 for name, c in CONFIGS.items():
+  if only and not any(o in name for o in only):
+    continue
   D = sum(c["dims"])
   eng = Engine(ModelSpec(D=D, K=c["K"], H=c["H"], M=c["M"], group_dims=c["dims"], gen_type=c["typ"]), device=dev)
   g = torch.Generator(device=dev).manual_seed(0)
