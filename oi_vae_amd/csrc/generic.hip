@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void enc_bwd_pre(int64_t B, int K, int S, cons
 __global__ __launch_bounds__(256) void enc_bwd_bias_final(const double* __restrict__ bias_part, int nblk, int K,
                                                           float* __restrict__ dbmu, float* __restrict__ dbsig,
                                                           uint32_t* __restrict__ rng, uint32_t* __restrict__ colmax,
-                                                          const uint32_t* __restrict__ max_part) {
+                                                          const uint32_t* __restrict__ max_part, int colmax_n) {
   __shared__ double sm[256];
   __shared__ uint32_t mx[256];
   const int j = blockIdx.x;
@@ -702,6 +702,9 @@ __global__ __launch_bounds__(256) void enc_bwd_bias_final(const double* __restri
     __syncthreads();
   }
   if (colmax != nullptr && threadIdx.x == 0) colmax[j] = mx[0];
+  // (the image's padding rows 2K .. colmax_n - 1 hold zeros whatever their scale: give them a defined one)
+  if (colmax != nullptr && j == 0)
+    for (int i = 2 * K + threadIdx.x; i < colmax_n; i += 256) colmax[i] = 0u;
   if (threadIdx.x == 0) {
     if (j < K) dbmu[j] = (float)sm[0]; else dbsig[j - K] = (float)sm[0];
   }
@@ -981,7 +984,8 @@ int oivae::encoder_bwd_run(const oivae_shape_t& s, const oivae_tensors_t* grads,
   OIVAE_LAUNCH_CHECK();
   hipLaunchKernelGGL(enc_bwd_bias_final, dim3((unsigned)(2 * s.K)), dim3(256), 0, st, bias_part, n_bias,
                      s.K, grads->enc_bmu, grads->enc_bsig, rng,
-                     h2 ? h2_bwd_colmax(x3_img, 2 * s.K, B) : (uint32_t*)nullptr, (const uint32_t*)max_part);
+                     h2 ? h2_bwd_colmax(x3_img, 2 * s.K, B) : (uint32_t*)nullptr, (const uint32_t*)max_part,
+                     (2 * s.K + 127) / 128 * 128);
   OIVAE_LAUNCH_CHECK();
   if (h2) {
     if (int rc = launch_encoder_bwd_x3(s, grads, X, dpre, B, x3_img, rng, st, /*colmax_ready=*/true)) return rc;

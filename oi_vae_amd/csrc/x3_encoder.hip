@@ -885,7 +885,9 @@ bool mfma_encoder_applies(const oivae_shape_t& s);  // mfma_encoder.hip
 bool x3_encoder_applies(const oivae_shape_t& s) {
   if (!mfma_encoder_applies(s)) return false;
   if (test_hooks().enc == 'f') return false;  // test hook: OIVAE_ENC=fp32 keeps the fp32 matrix instructions
-  return (2 * s.K) % 128 == 0 && s.D % 32 == 0;
+  // 2K a multiple of 64: the kernels' column tile is 128 wide and the images are padded to it with zero rows, so
+  // 2K = 64, 192, ... leave half a tile's matrix work unused -- under kernels that wait for HBM either way
+  return (2 * s.K) % 64 == 0 && s.D % 32 == 0;
 }
 
 static inline int x3_rows_pad(int J) { return (J + 127) / 128 * 128; }
