@@ -126,12 +126,17 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
   w->x3_img = reinterpret_cast<uint32_t*>(take(x3_encoder_ws_bytes(s, B)));
   w->ranges = reinterpret_cast<uint32_t*>(take(256));
   w->enc_bwd_part = reinterpret_cast<float*>(take(enc_bwd_part_bytes(s, B, x3_encoder_bwd_applies(s, B))));
-  w->x3_z = reinterpret_cast<uint32_t*>(take((plan.mfma && s.K == 64) ? ((N + 31) / 32) * 24 * 1024 : 0));
+  const bool z_img = plan.mfma && (s.K == 64 || dec_pad64_applies(s));   // (the padded shapes run with K = 64)
+  w->x3_z = reinterpret_cast<uint32_t*>(take(z_img ? ((N + 31) / 32) * 24 * 1024 : 0));
   w->small = take(plan_small_step(s, B, S).ws_bytes);
-  w->dec_zmax = reinterpret_cast<uint32_t*>(take((plan.mfma && s.K == 64) ? 1024 : 0));
+  w->dec_zmax = reinterpret_cast<uint32_t*>(take(z_img ? 1024 : 0));
   {
     const int64_t a2 = plan.mfma ? mfma_decoder_acc2_bytes(s, N, plan.chunks) : 0;
     w->dec_acc2 = a2 > 0 ? reinterpret_cast<float*>(take(a2)) : nullptr;
+  }
+  {
+    const int64_t pb = plan.mfma ? dec_pad64_bytes(s, N, plan.chunks) : 0;
+    w->dec_pad = pb > 0 ? reinterpret_cast<float*>(take(pb)) : nullptr;
   }
   w->total_bytes = off;
   if (p && bytes < off)

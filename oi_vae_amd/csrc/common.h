@@ -66,6 +66,7 @@ struct Workspace {
   uint32_t* dec_zmax;                      // dec_x3_64s/g: 256 per-workgroup maxima of |z| (dec_absmax_f32 -> x3_split_z)
   char*   small;                           // small_step.hip: per-block gradient slabs, KL / log-lik partials, ticket counter
   float*  dec_acc2;                        // dec_x3_64s: second-level slabs of its weight-gradient waves (nullptr: not needed)
+  float*  dec_pad;                         // dec_pad64.hip: zero-padded parameters, gradients, slabs, z and dz of the {32,64} mixes (nullptr: other shapes)
   int64_t total_bytes;
 };
 
@@ -111,6 +112,13 @@ struct DecPlan {
 
 DecPlan plan_decoder(const oivae_shape_t& s, int64_t N);
 int64_t mfma_decoder_acc2_bytes(const oivae_shape_t& s, int64_t N, int chunks);   // mfma_decoder.hip
+// dec_pad64.hip: K, H, M in {32, 64} (not all 64) with 64 outputs per group run through the all-64 fp16-term kernel on
+// zero-padded copies
+bool dec_pad64_applies(const oivae_shape_t& s);
+int64_t dec_pad64_bytes(const oivae_shape_t& s, int64_t N, int chunks);
+int launch_decoder_pad64(const oivae_shape_t& s, const oivae_tensors_t* params, const oivae_tensors_t* grads,
+                         const float* X, int64_t B, int32_t S, const float* z, float gen_sig_off, float* dz,
+                         Workspace& w, hipStream_t st);
 // small_step.hip: the whole step of a small model in one launch
 struct SmallPlan { bool ok; int RB, NR, GR, nblk; int64_t P; int64_t ws_bytes; size_t lds_bytes; };
 SmallPlan plan_small_step(const oivae_shape_t& s, int64_t B, int32_t S);

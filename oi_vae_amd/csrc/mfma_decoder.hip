@@ -550,7 +550,7 @@ static int launch_one(const MfmaDecArgs& a, int G, int chunks, hipStream_t st) {
 // dec_x3_64s: bytes of second-level slabs (one of 128 x 64 floats per weight-gradient wave) -- 0 when a launch has no
 // more rounds than one flush interval, or when another kernel runs
 int64_t mfma_decoder_acc2_bytes(const oivae_shape_t& s, int64_t N, int chunks) {
-  if (!dec_all64(s)) return 0;
+  if (!dec_all64(s) && !dec_pad64_applies(s)) return 0;   // (the padded shapes run as all-64)
   const int64_t ntiles = (N + 31) / 32;
   const int64_t nrounds = (ntiles + 4 * (int64_t)chunks - 1) / (4 * (int64_t)chunks);
   if (nrounds <= kFlushRounds) return 0;
@@ -573,6 +573,11 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   const int64_t N = B * (int64_t)S;
   if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(z) & 15) || (s.D % 4))
     return fail(OIVAE_E_ARG, "MFMA decoder: X and z must be 16-byte aligned");
+  const char* dec_env = test_hooks().dec[0] ? test_hooks().dec : nullptr;
+  // K, H, M in {32, 64} with 64 outputs per group: the all-64 fp16-term kernel on zero-padded copies (dec_pad64.hip),
+  // unless a test hook asks for another family (OIVAE_DEC=v1: dec_mfma<K, H, M, DG> below, their cross-check)
+  if (dec_pad64_applies(s) && w.dec_pad != nullptr && (dec_env == nullptr || dec_env[0] == 's' || dec_env[0] == 'g'))
+    return launch_decoder_pad64(s, params, grads, X, B, S, z, gen_sig_off, dz, w, st);
   const DecLayout L = dec_layout(s);
   const int chunks = w.n_chunks;
   MfmaDecArgs a;
@@ -595,7 +600,6 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   a.rng = nullptr;
   a.acc2 = nullptr;
   int rc;
-  const char* dec_env = test_hooks().dec[0] ? test_hooks().dec : nullptr;
   // test hooks: OIVAE_DEC=v1 the layer-by-layer fp32 template kernel (which also serves launches whose dz image
   // exceeds the 32-bit byte offsets of dec_mfma64_v4's atomics, N*K*4 >= 2^32), OIVAE_DEC=v4 the fp32
   // composed-first-layer kernel, OIVAE_DEC=x3 the single-wave-per-SIMD split-bf16 kernel, OIVAE_DEC=p the all-bf16

@@ -319,6 +319,16 @@ def main():
              dict(D=128, K=64, H=64, M=64, gen_type="mlp", group_dims=[64] * 2), seed=8,
              steps=[dict(B=160, S=1, c=1.0, t=1e-4)] * 2,
              lr=1e-3, Ws_lr=1e-4, lam=1, prior_rows="1")
+  # two-layer shapes with 32-wide latent / group input / hidden layer and 64 outputs per group (run through the all-64
+  # kernel on zero-padded copies, csrc/dec_pad64.hip): an odd number of groups, ragged rows
+  run_config("c4_pad32",
+             dict(D=192, K=32, H=32, M=32, gen_type="mlp", group_dims=[64] * 3), seed=31,
+             steps=[dict(B=96, S=1, c=1.0, t=1e-4)] * 2 + [dict(B=45, S=2, c=0.5, t=1e-4)],
+             lr=1e-3, Ws_lr=1e-4, lam=1, prior_rows="1")
+  run_config("c4_pad_m32",
+             dict(D=128, K=64, H=64, M=32, gen_type="mlp", group_dims=[64] * 2), seed=32,
+             steps=[dict(B=64, S=1, c=1.0, t=1e-4)] * 2,
+             lr=1e-3, Ws_lr=1e-4, lam=1, prior_rows="1")
   # odd two-layer shapes, S=2
   run_config("c4_mixed",
              dict(D=24, K=16, H=8, M=24, gen_type="mlp", group_dims=[5, 12, 7]), seed=9,

@@ -89,9 +89,11 @@ def test_mfma_kernels_agree_with_generic_kernels(tmp_path):
 @pytest.mark.parametrize("K,H,M,dg", [(k, h, m, d) for k in (32, 64) for h in (32, 64) for m in (32, 64) for d in (32, 64)
                                       if (k, h, m, d) not in ((64, 64, 64, 64), (32, 32, 32, 32))])
 def test_mixed_32_64_generators_on_the_matrix_decoder(K, H, M, dg):
-  """Two-layer generators whose four dimensions are 32 or 64 in any combination run dec_mfma<K, H, M, DG> (fp32 matrix
-  instruction, dz transposed); the shape-generic kernels on the same inputs are the check: ragged row count, two
-  samples, scalars 1e-5, every gradient tensor 2e-5 of its scale."""
+  """Two-layer generators whose four dimensions are 32 or 64 in any combination take the matrix decoders (dz
+  transposed): with 64 outputs per group the all-64 fp16-term kernel on zero-padded copies (csrc/dec_pad64.hip), with
+  32 outputs dec_mfma<K, H, M, DG> on the fp32 matrix instruction.  The shape-generic kernels on the same inputs are the
+  check -- and, for the padded shapes, dec_mfma (OIVAE_DEC=v1) as a third family: ragged row count, two samples,
+  scalars 1e-5, every gradient tensor 2e-5 of its scale."""
   G, B, S = 7, 150, 2   # 300 rows = 9.4 wave tiles
   lib = _lib.load()
   spec_eng = _engine(G, dg, K, H, M, seed=11)
@@ -101,23 +103,29 @@ def test_mixed_32_64_generators_on_the_matrix_decoder(K, H, M, dg):
   X = torch.rand(B, G * dg, generator=g, device="cuda")
   eps = torch.randn(S, B, K, generator=g, device="cuda")
   res = []
+  families = [{}, {"OIVAE_FORCE_GENERIC": "1"}] + ([{"OIVAE_DEC": "v1"}] if dg == 64 else [])
   try:
-    for generic in (False, True):
-      _lib.set_test_hooks(OIVAE_FORCE_GENERIC="1" if generic else None)
+    for env in families:
+      _lib.set_test_hooks(**env)
       eng = _engine(G, dg, K, H, M, seed=11)
+      eng.flat_grads.fill_(float("nan"))      # every gradient element must be written (the un-padding copies blocks)
       out = eng.forward_backward(X, eps, 0.7)
       torch.cuda.synchronize()
       res.append((eng.flat_grads.clone(), out["scalars"].clone(), eng))
+      _lib.set_test_hooks(**{k: None for k in env})
   finally:
-    _lib.set_test_hooks(OIVAE_FORCE_GENERIC=None)
-  (ga, sa, eng), (gb, sb, _) = res
-  assert ((sa[:6] - sb[:6]).abs() / sb[:6].abs().clamp(min=1)).max().item() < 1e-5
-  for name in eng.seg_off:
-    o, n = eng.seg_off[name], eng.seg_numel[name]
-    if n == 0:
-      continue
-    err = ((ga[o:o + n] - gb[o:o + n]).abs().max() / gb[o:o + n].abs().max().clamp(min=1e-30)).item()
-    assert err < 2e-5, (name, err)
+    _lib.set_test_hooks(OIVAE_FORCE_GENERIC=None, OIVAE_DEC=None)
+  ga, sa, eng = res[0]
+  for name in eng.seg_off:   # (the alignment gaps between the segments keep the fill)
+    assert torch.isfinite(ga[eng.seg_off[name]:eng.seg_off[name] + eng.seg_numel[name]]).all(), name
+  for gb, sb, _ in res[1:]:
+    assert ((sa[:6] - sb[:6]).abs() / sb[:6].abs().clamp(min=1)).max().item() < 1e-5
+    for name in eng.seg_off:
+      o, n = eng.seg_off[name], eng.seg_numel[name]
+      if n == 0:
+        continue
+      err = ((ga[o:o + n] - gb[o:o + n]).abs().max() / gb[o:o + n].abs().max().clamp(min=1e-30)).item()
+      assert err < 2e-5, (name, err)
 
 
 def test_full_scale_batch_equals_mean_of_half_batches():

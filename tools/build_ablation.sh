@@ -10,6 +10,6 @@ DEFS=""
 for t in ${TAGS//+/ }; do DEFS="$DEFS -DOIVAE_ABL_$t"; done
 /opt/rocm/bin/hipcc -O3 -fno-slp-vectorize -fPIC --offload-arch=gfx950 -std=c++17 $DEFS -c "$C/mfma_decoder.hip" -o "$HERE/tools/probe/abl_$TAGS.o"
 /opt/rocm/bin/hipcc -O3 -fno-slp-vectorize -fPIC --offload-arch=gfx950 -std=c++17 $DEFS -c "$C/xcheck_decoders.hip" -o "$HERE/tools/probe/ablx_$TAGS.o"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$C/build/api.o" "$C/build/prox.o" "$C/build/generic.o" "$HERE/tools/probe/abl_$TAGS.o" "$HERE/tools/probe/ablx_$TAGS.o" "$C/build/small_step.o" \
-  "$C/build/mfma_encoder.o" "$C/build/flat_decoder.o" "$C/build/x3_encoder.o" "$C/build/noalloc.o" -o "$HERE/tools/probe/liboivae_abl_$TAGS.so"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls "$C"/build/*.o | grep -v -e mfma_decoder -e xcheck_decoders -e waittest -e stamps) \
+  "$HERE/tools/probe/abl_$TAGS.o" "$HERE/tools/probe/ablx_$TAGS.o" -o "$HERE/tools/probe/liboivae_abl_$TAGS.so"
 rm -f "$HERE/tools/probe/abl_$TAGS.o" "$HERE/tools/probe/ablx_$TAGS.o"
