@@ -9,4 +9,5 @@ cd $ROOT
 bash tools/pmc_collect.sh $R/pmc
 timeout -k 10 300 python3 tools/shard_sweep.py > $R/shard_sweep.jsonl 2> $R/shard.err
 timeout -k 10 300 python3 tools/config_steps.py > $R/config_steps.jsonl 2> $R/config.err
+timeout -k 10 300 python3 tools/mixed_dims.py > $R/mixed_dims.jsonl 2> $R/mixed.err
 ls $R $R/prof | head -40
