@@ -11,4 +11,6 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 n = sys.argv[1] if len(sys.argv) > 1 else "5000"
 sys.argv = ["bars", "--iterations", n, "--out", "/tmp/out_bars_prof", "--log-every", "100000"]
 cProfile.run('runpy.run_path(%r, run_name="__main__")' % os.path.join(root, "scripts", "bars_data_oivae.py"), "/tmp/bars_prof.out")
-pstats.Stats("/tmp/bars_prof.out").sort_stats("cumulative").print_stats(30)
+st = pstats.Stats("/tmp/bars_prof.out")
+st.sort_stats("cumulative").print_stats("oi_vae_amd|scripts|bars", 40)
+st.sort_stats("tottime").print_stats(25)
