@@ -263,7 +263,7 @@ int oivae_adam_f32(float* p, const float* g, float* m, float* v, int64_t n,
  * (bars_data_oivae.py:20-33, mo_mo_mocap_oivae.py:26-35): encoder forward + KL + samples, grouped decoder forward /
  * backward + log-likelihood, weight prior, penalty, the six scalars, encoder backward and -- with do_optimizers --
  * Adam over every non-Ws parameter (bars_data_oivae.py:233-239), SGD on Ws and, with do_prox, the proximal step
- * (lib/oivae.py:76-79), the last two bit for bit as oivae_sgd_prox_f32.  One memset node and one kernel instead of the
+ * (lib/oivae.py:76-79), the last two bit for bit as oivae_sgd_prox_f32.  One kernel (+ a 4-byte memset node, see ticket_is_zero) instead of the
  * two dozen launches of the entry points above (which stay valid for the same shapes and give the same results to
  * rounding; these models are launch-bound).  `grads` is written completely either way; mu_q, sig_q [B,K], z [S*B,K]
  * and `out` hold the PRE-update values (lib/oivae.py:81-90).  adam_m / adam_v: Adam's moments, one array per tensor
@@ -273,7 +273,11 @@ int oivae_adam_f32(float* p, const float* g, float* m, float* v, int64_t n,
  * fixed order: results are bit-reproducible run to run.
  * Accepted (oivae_small_step_applies says 1): single-layer generators (OIVAE_GEN_LINEAR, OIVAE_GEN_TANH_LINEAR),
  * H in {1,2,4,8}, K <= 32, D <= 256, groups of at most 16 outputs, S <= 64, S*B <= 8192, at most 2^17 parameters;
- * else OIVAE_E_SHAPE.  Workspace: oivae_workspace_bytes(shape, B, S). */
+ * else OIVAE_E_SHAPE.  Workspace: oivae_workspace_bytes(shape, B, S).
+ * ticket_is_zero: 0 is always right (the call zeroes its workgroup ticket in the workspace first: a 4-byte memset
+ * node).  Nonzero skips that node: the caller then vouches that the last thing that wrote this workspace's small-step
+ * region was a COMPLETED call of this entry point with the same shape, B and S (the kernel leaves the ticket at
+ * zero); anything else -- a fresh or re-used allocation, another B or S, a failed call -- needs 0. */
 int oivae_small_step_applies(const oivae_shape_t* shape, int64_t B, int32_t S);
 int oivae_small_step_f32(const oivae_shape_t* shape, const oivae_tensors_t* params, const oivae_tensors_t* grads,
                          const float* X, int64_t B, int32_t S, const float* eps, float c, float sig_off,
@@ -283,7 +287,7 @@ int oivae_small_step_f32(const oivae_shape_t* shape, const oivae_tensors_t* para
                          int32_t do_optimizers, const oivae_tensors_t* adam_m, const oivae_tensors_t* adam_v,
                          float lr, float beta1, float beta2, float adam_eps, int32_t adam_step,
                          float ws_lr, float t, int32_t do_prox, uint8_t* zero_mask, float* row_norms,
-                         void* workspace, int64_t workspace_bytes, void* stream);
+                         int32_t ticket_is_zero, void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -87,7 +87,7 @@ def bind(path):
   L.oivae_small_step_applies.restype = ctypes.c_int
   L.oivae_small_step_f32.argtypes = [PS, PT, PT, c_vp, c_i64, c_i32, c_vp, c_f, c_f, c_vp, c_vp, c_i32, c_f, c_f, c_f,
                                      c_vp, c_vp, c_vp, c_vp, c_i32, PT, PT, c_f, c_f, c_f, c_f, c_i32,
-                                     c_f, c_f, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]
+                                     c_f, c_f, c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp]
   L.oivae_small_step_f32.restype = ctypes.c_int
   L.oivae_check_errors.argtypes = [c_vp]
   L.oivae_check_errors.restype = ctypes.c_int

@@ -448,7 +448,7 @@ extern "C" int oivae_small_step_f32(const oivae_shape_t* shape, const oivae_tens
                                     float* mu_q, float* sig_q, float* z, oivae_scalars_t* out,
                                     int32_t do_optimizers, const oivae_tensors_t* adam_m, const oivae_tensors_t* adam_v,
                                     float lr, float beta1, float beta2, float adam_eps, int32_t adam_step,
-                                    float ws_lr, float t, int32_t do_prox, uint8_t* zero_mask, float* row_norms,
+                                    float ws_lr, float t, int32_t do_prox, uint8_t* zero_mask, float* row_norms, int32_t ticket_is_zero,
                                     void* workspace, int64_t workspace_bytes, void* stream) {
   if (int rc = check_shape(shape)) return rc;
   if (!params || !grads || !X || !eps || !prior_mu || !prior_sigma || !mu_q || !sig_q || !z || !out || !workspace)
@@ -523,7 +523,10 @@ extern "C" int oivae_small_step_f32(const oivae_shape_t* shape, const oivae_tens
   a.ob2 = off; off += s.D;
   a.oLs = off; off += s.D;
   a.oWs = off; off += (int64_t)s.G * s.K * s.H;
-  OIVAE_HIP_CHECK(hipMemsetAsync(a.counter, 0, 4, st));   // (a workspace may hold anything; the kernel lowers it again itself)
+  // a workspace may hold anything: the ticket counter is zeroed ahead of the kernel (a 4-byte memset node, ~4 us of a
+  // 0.03 ms step) unless the caller vouches that this workspace's last user was a completed call of this entry point
+  // with the same shape, B and S -- the kernel's last workgroup lowers the counter again itself
+  if (!ticket_is_zero) OIVAE_HIP_CHECK(hipMemsetAsync(a.counter, 0, 4, st));
 #define OIVAE_SMALL_LAUNCH(HH)                                                                                    \
   {                                                                                                               \
     OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_step_kernel<HH>),                     \

@@ -209,6 +209,7 @@ class Engine:
     return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
   def _workspace(self, B, S):
+    self._small_ticket = None   # whoever asks for the workspace may write it: only small_step re-arms this (see there)
     key = (B, S)
     if self._ws_key != key:
       nbytes = self.lib.oivae_workspace_bytes(ctypes.byref(self._shape), B, S)
@@ -349,6 +350,7 @@ class Engine:
       prior_rows = prior_mu.size(0)
       if prior_rows not in (1, B) or prior_sigma.size(0) != prior_rows:
         raise ValueError("prior_z must have 1 or B=%d rows, got %d" % (B, prior_rows))
+      last_ticket = getattr(self, "_small_ticket", None)
       ws = self._workspace(B, S)
       mu_q = torch.empty(B, s.K, dtype=torch.float32, device=self.device)
       sig_q = torch.empty(B, s.K, dtype=torch.float32, device=self.device)
@@ -366,13 +368,19 @@ class Engine:
         am, av = ctypes.byref(self._adam_mt[1]), ctypes.byref(self._adam_mt[2])
       else:
         am = av = None
+      # the kernel's workgroup ticket lives in the workspace; the library zeroes it first (a memset node) unless told that
+      # this very workspace last went through a completed small step of the same B and S (include/oivae_hip.h)
+      # (every other user of the workspace goes through _workspace(), which disarms it)
+      key = (ws.data_ptr(), B, S)
+      ticket_ok = 1 if last_ticket == key else 0
       _lib.check(self._timed("small_step", lambda: self.lib.oivae_small_step_f32(
         ctypes.byref(self._shape), ctypes.byref(self._pt), ctypes.byref(self._gt), X.data_ptr(), B, S, eps.data_ptr(),
         float(c), float(sig_off), prior_mu.data_ptr(), prior_sigma.data_ptr(), prior_rows, float(gen_sig_off),
         float(sigma_theta), float(lam), mu_q.data_ptr(), sig_q.data_ptr(), z.data_ptr(), self.scalars.data_ptr(),
         1 if optimizers else 0, am, av, float(lr), float(betas[0]), float(betas[1]), float(adam_eps), max(self.adam_t, 1),
         float(Ws_lr), float(prox_step_size), 1 if do_prox else 0, self.zero_mask.data_ptr(), self.row_norms.data_ptr(),
-        ws.data_ptr(), self._ws_bytes, self._stream())), "oivae_small_step_f32")
+        ticket_ok, ws.data_ptr(), self._ws_bytes, self._stream())), "oivae_small_step_f32")
+      self._small_ticket = key     # the call was accepted and queued: its kernel leaves the ticket at zero
     return dict(mu_q=mu_q, sig_q=sig_q, z=z, scalars=self.scalars, X=X, eps=eps)
 
   def _const(self, name, val):

@@ -87,3 +87,35 @@ def test_small_step_refuses_what_it_does_not_cover():
   assert not eng.small_step_applies(64, 1)
   with pytest.raises(_lib.OivaeError):
     eng.small_step(torch.rand(64, 128), torch.randn(1, 64, 64), 1.0, 1e-4, lr=1e-3, Ws_lr=1e-4)
+
+
+def test_small_step_ticket_survives_a_foreign_workspace_and_interleaved_calls():
+  """The kernel's "last workgroup" ticket lives in the workspace.  The entry point zeroes it first unless the caller
+  vouches for it (ticket_is_zero, include/oivae_hip.h); the engine vouches only when the same workspace went through a
+  completed small step of the same B and S with nothing in between.  Here: a workspace full of 0xff, then steps that
+  alternate with the multi-launch path at another batch size (which re-carves the same allocation) -- every small step
+  must give the bits of a fresh engine doing the same steps without the shortcut."""
+  z, spec = load("c2_mocap")
+  X, eps, c, t = z["step0/X"], z["step0/eps"], float(z["step0/c"]), float(z["step0/t"])
+  kw = dict(lr=spec["lr"], Ws_lr=spec["Ws_lr"], sigma_theta=spec["sigma_theta"], lam=spec["lam"])
+
+  def run(shortcut):
+    eng = _engine(spec)
+    eng.load_params(params_at(z, spec, "init/"))
+    eng._workspace(X.shape[0], eps.shape[0]).fill_(0xff)          # a foreign workspace: the ticket word is garbage
+    outs = []
+    for rep in range(6):
+      if not shortcut:
+        eng._small_ticket = None                                    # always the memset node
+      if rep == 3:   # another path, another batch size, the same allocation
+        eng.forward_backward(X[:37], eps[:, :37], c)
+      out = eng.small_step(X, eps, c, t, **kw)
+      outs.append((out["scalars"].clone(), eng.flat_params.clone()))
+    torch.cuda.synchronize()
+    return outs, eng
+
+  a, eng = run(True)
+  b, _ = run(False)
+  assert eng._small_ticket is not None                              # the shortcut was armed at the end
+  for (sa, pa), (sb, pb) in zip(a, b):
+    assert torch.equal(sa, sb) and torch.equal(pa, pb)
