@@ -78,6 +78,7 @@ class FirstLayerSparseDecoder(object):
     for m in self.latent_to_group_maps:
       m.cuda()
     self._flat = None
+    self._packed()   # pack now: an optimizer built after .cuda() then holds the views the proximal kernel updates
     return self
 
   def _packed(self):

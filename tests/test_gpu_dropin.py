@@ -169,3 +169,26 @@ def test_evaluate_gives_the_steps_terms_without_side_effects(name):
   # and a training step afterwards is still the golden one
   info = vae.step(X, float(z["step0/t"]), eps.shape[0], eps=eps)
   assert rel_err(gen.Ws.grad.cpu().numpy(), z["step0/grad/Ws"]) < 2e-5
+
+
+def test_autoencoder_variant_driver_trains_and_sparsifies(tmp_path):
+  """scripts/data_vs_test_loss_autoencoder.py (counterpart of the reference's driver of the same name) for a few hundred
+  epochs at two training-set sizes: the reconstruction loss falls, and with lambda > 0 the proximal kernel zeroes
+  connections exactly while lambda = 0 zeroes none."""
+  import importlib.util
+  import json
+  import os
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  spec = importlib.util.spec_from_file_location("ae_driver", os.path.join(root, "scripts", "data_vs_test_loss_autoencoder.py"))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  out = tmp_path / "ae.json"
+  res = mod.main(["--epochs", "300", "--train-sizes", "64", "--lams", "0.0", "0.1", "--test-samples", "256", "--out", str(out)])
+  saved = json.load(open(out))
+  assert len(saved["results"]) == 2 and saved["lams"] == [0.0, 0.1]
+  by_lam = {r["lam"]: r for r in res}
+  for r in res:
+    assert r["train_loss"][-1] < 0.5 * r["train_loss"][0], (r["lam"], r["train_loss"][0], r["train_loss"][-1])
+    assert all(v == v for v in r["test_loss"])
+  assert by_lam[0.0]["zero_connections"] == 0
+  assert by_lam[0.1]["zero_connections"] > 0
