@@ -181,6 +181,16 @@ class OIVAE(object):
       parallel.reduce_scalars_(scalars, self.process_group)
     return self._info(out, scalars)
 
+  def heldout_loglik(self, X, mc_samples, eps=None):
+    """Held-out log-likelihood term of a batch, E_q log p(x | z) averaged over the batch (`loglik_term` of `evaluate`),
+    evaluated on THIS rank only -- for test sets every rank holds whole (no reduction over ranks)."""
+    dp = self.data_parallel
+    self.data_parallel = False
+    try:
+      return self.evaluate(X, mc_samples, eps)['loglik_term']
+    finally:
+      self.data_parallel = dp
+
   @staticmethod
   def _info(out, scalars):
     return {

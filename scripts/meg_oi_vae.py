@@ -45,6 +45,8 @@ def main(argv=None):
   ap.add_argument("--labels", type=int, default=44)
   ap.add_argument("--frames", type=int, default=32768)
   ap.add_argument("--log-every", type=int, default=50)
+  ap.add_argument("--test-fraction", type=float, default=0.1,
+                  help="frames held out for the test log-likelihood the reference leaves stubbed (meg_oi_vae.py:258-260)")
   ap.add_argument("--out", default="out_meg")
   args = ap.parse_args(argv)
 
@@ -67,7 +69,9 @@ def main(argv=None):
   exp = Experiment(dim_x=X.shape[1], dim_z=args.dim_z, group_dims=group_output_dims, group_input_dim=1,
                    gen_type="linear", lr=1e-3, Ws_lr=1e-6, lam=1.0, prior_rows=1,
                    device=torch.device("cuda", local_rank))
-  Xd = torch.from_numpy(X).to(exp.device)
+  n_test = int(X.shape[0] * args.test_fraction)
+  Xtest = torch.from_numpy(X[X.shape[0] - n_test:]).to(exp.device) if n_test else None
+  Xd = torch.from_numpy(X[:X.shape[0] - n_test]).to(exp.device)
   gen = torch.Generator().manual_seed(1)
   done = False
   for epoch in range(args.epochs):
@@ -84,9 +88,24 @@ def main(argv=None):
         break
     if done:
       break
+  # test log-likelihood: the held-out frames through the trained model, no gradient / optimizer / proximal side effect
+  # (every rank evaluates the same frames in batches of 4096; per-frame average of log p(x | z), z ~ q(z | x))
+  test_log_lik = None
+  if Xtest is not None and Xtest.size(0) > 0:
+    tot, cnt = 0.0, 0
+    for lo in range(0, Xtest.size(0), batch_size):
+      xb = Xtest[lo:lo + batch_size]
+      tot += float(exp.vae.heldout_loglik(xb, mc_samples)) * xb.size(0)
+      cnt += xb.size(0)
+    test_log_lik = tot / cnt
   if rank == 0:
     C = exp.save_artifacts(args.out, 'meg')
     print('connectivity matrix %s, %d of %d connections exactly zero' % (C.shape, (C == 0).sum(), C.size))
+    if test_log_lik is not None:
+      print("test log-lik: %.4f per frame over %d held-out frames" % (test_log_lik, Xtest.size(0)))
+      import json
+      with open(os.path.join(args.out, 'meg_test_log_lik.json'), 'w') as f:
+        json.dump({'test-log-lik': test_log_lik, 'frames': int(Xtest.size(0)), 'iterations': exp.iteration}, f)
   if world > 1:
     torch.distributed.destroy_process_group()
   return exp

@@ -58,4 +58,7 @@ def test_meg_like_driver(tmp_path):
   out = str(tmp_path / "meg")
   _load("meg_oi_vae").main(["--labels", "12", "--frames", "10000", "--max-iterations", "8", "--log-every", "4", "--out", out])
   C, s = _summary(out, "meg")
-  assert C.shape == (12, 10) and s["iterations"] == 8        # 10000 frames: batches of 4096, 4096, 1808
+  assert C.shape == (12, 10) and s["iterations"] == 8        # 9000 training frames: batches of 4096, 4096, 808
+  import json
+  t = json.load(open(os.path.join(out, "meg_test_log_lik.json")))   # the evaluation the reference leaves stubbed
+  assert t["frames"] == 1000 and np.isfinite(t["test-log-lik"])
