@@ -183,3 +183,36 @@ def test_first_layer_sparse_decoder_has_no_cpu_fallback():
   assert dec.group_lasso_penalty().item() > 0
   with pytest.raises(oi.OivaeError):
     dec.proximal_step(0.1)                             # the proximal step is the HIP kernel or nothing
+
+
+def test_bench_reports_pmc_traffic_only_for_the_profiled_decoder_sources(tmp_path, monkeypatch):
+  """bench.py's `roofline.traffic` comes from committed rocprofv3 PMC passes; a profile taken from OTHER decoder sources
+  must give null (a stale figure is worse than none).  The committed file matches this tree; a copy with another stamp,
+  or one that lacks the kernel, does not count."""
+  import json
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  import bench
+  t = bench.pmc_traffic()
+  assert t is not None and t.get("bytes"), "profiles/pmc_per_kernel_latest.json is stale: re-run tools/pmc_collect.sh + pmc_summarize.py"
+  assert t["decoder_source_digest"] == bench.decoder_source_digest()
+  assert 17.2e9 < t["read_bytes"] < 23e9 and 8.6e9 < t["write_bytes"] < 10e9     # X once + re-reads of z; dz adds + slabs
+  d = json.load(open(os.path.join(bench.ROOT, bench.PMC_FILE)))
+  d["_decoder_source_digest"] = "0" * 16
+  stale = tmp_path / "pmc.json"
+  stale.write_text(json.dumps(d))
+  monkeypatch.setattr(bench, "PMC_FILE", str(stale))
+  t = bench.pmc_traffic()
+  assert t["bytes"] is None and t["stale"] is True
+  stale.write_text(json.dumps({"_decoder_source_digest": bench.decoder_source_digest()}))
+  assert bench.pmc_traffic() is None
+
+
+def test_bench_flop_accounting_follows_the_survey():
+  """SURVEY 8(d): 3 G (2KH + 2HM + 2M D_g) = 75.50 MFLOP per row for the decoder, 2 (4 D K) = 33.55 for the encoder;
+  the issued 16-bit flops are 2.0 x the algorithmic ones (6 composed products of 9, three terms each)."""
+  import bench
+  assert abs(bench.decoder_flops_per_row() / 1e6 - 75.50) < 0.01
+  assert abs(bench.encoder_flops_per_row() / 1e6 - 33.55) < 0.01
+  rows = bench.GLOBAL_BATCH
+  assert abs(bench.decoder_f16_flops(rows) / (bench.decoder_flops_per_row() * rows) - 2.0) < 1e-9
+  assert abs((bench.decoder_flops_per_row() + bench.encoder_flops_per_row()) * rows / 1e12 - 7.147) < 0.001
