@@ -1,0 +1,99 @@
+"""Seeded random shapes through the default kernel choice and through the shape-generic kernels (OIVAE_FORCE_GENERIC):
+whatever path a shape is served by -- fp16-term or fp32 matrix decoders, padded 32/64 mixes, dec_single, the flat
+many-small-groups path, h2 / fp32 / generic encoder GEMMs, ragged groups, batches that are no multiple of anything --
+one step must give the same scalars (1e-5) and gradients (2e-5 of each tensor's scale), and the optimizers + proximal
+step the same zero set.  The shapes are drawn, not chosen: the point is the combinations nobody wrote a test for."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oi_vae_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _draw(seed):
+  r = np.random.default_rng(seed)
+  kind = r.choice(["linear", "tanh_linear", "mlp", "mlp_mix", "small_groups"])
+  S = int(r.choice([1, 1, 2, 3]))
+  B = int(r.choice([1, 7, 33, 64, 100, 257]))
+  if kind == "mlp_mix":      # the matrix decoders' shapes: every dimension 32 or 64
+    K, H, M = (int(r.choice([32, 64])) for _ in range(3))
+    dg = int(r.choice([32, 64]))
+    G = int(r.integers(1, 6))
+    return dict(gen_type="mlp", K=K, H=H, M=M, dims=[dg] * G, B=B, S=S)
+  if kind == "small_groups":   # towards the flat path: K a multiple of 128, G H a multiple of 128, uniform tiny groups
+    H = int(r.choice([4, 8]))
+    return dict(gen_type="linear", K=128, H=H, M=0, dims=[int(r.choice([2, 4]))] * (128 // H * int(r.integers(1, 3))),
+                B=int(r.choice([32, 96])), S=1)
+  K = int(r.choice([1, 2, 3, 8, 10, 16, 31, 32, 40]))
+  H = int(r.choice([1, 2, 4, 8, 16, 5]))
+  G = int(r.integers(1, 9))
+  dims = [int(x) for x in r.integers(1, 40, G)]
+  if r.random() < 0.5:       # rows of X 16-byte aligned: the matrix-core encoders apply
+    dims[-1] += (-sum(dims)) % 4
+  M = int(r.choice([8, 24, 33])) if kind == "mlp" else 0
+  return dict(gen_type=kind if kind != "mlp" else "mlp", K=K, H=H, M=M, dims=dims, B=B, S=S)
+
+
+def _run(cfg, seed, generic):
+  from oi_vae_amd import Engine, ModelSpec
+  _lib.set_test_hooks(OIVAE_FORCE_GENERIC="1" if generic else None)
+  try:
+    D = sum(cfg["dims"])
+    eng = Engine(ModelSpec(D=D, K=cfg["K"], H=cfg["H"], M=cfg["M"], group_dims=cfg["dims"], gen_type=cfg["gen_type"]),
+                 device="cuda:0")
+    g = torch.Generator(device="cuda").manual_seed(1000 + seed)
+    for n, t in eng.p.items():
+      if n == "log_sigma":
+        t.copy_(torch.log(10 ** (torch.rand(t.shape, generator=g, device="cuda") * 1.5 - 2.0)))
+      elif n == "Ws":
+        t.copy_(torch.randn(t.shape, generator=g, device="cuda"))
+      else:
+        t.copy_((torch.rand(t.shape, generator=g, device="cuda") * 2 - 1) / max(1, t.shape[-1]) ** 0.5)
+    if seed % 3 == 0 and eng.p["Ws"].size(0) > 1:
+      eng.p["Ws"][0] = 0.0      # a dead group
+    X = torch.rand(cfg["B"], D, generator=g, device="cuda")
+    eps = torch.randn(cfg["S"], cfg["B"], cfg["K"], generator=g, device="cuda")
+    out = eng.forward_backward(X, eps, 0.7)
+    grads, sc = eng.flat_grads.clone(), out["scalars"].clone()
+    t = float(torch.sqrt((eng.p["Ws"] ** 2).sum(-1)).median())
+    eng.adam_step(1e-3)
+    eng.sgd_prox_step(1e-4, t)
+    torch.cuda.synchronize()
+    eng.check_errors()
+    return eng, grads, sc, eng.flat_params.clone(), eng.zero_mask.clone()
+  finally:
+    _lib.set_test_hooks(OIVAE_FORCE_GENERIC=None)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OIVAE_FUZZ_SEEDS", "48"))))   # (a one-off run of 800 seeds: all green)
+def test_random_shape_default_path_matches_generic_kernels(seed):
+  cfg = _draw(seed)
+  eng, ga, sa, pa, za = _run(cfg, seed, generic=False)
+  _, gb, sb, pb, zb = _run(cfg, seed, generic=True)
+  assert ((sa[:6] - sb[:6]).abs() / sb[:6].abs().clamp(min=1)).max().item() < 1e-5, (cfg, sa[:6].tolist(), sb[:6].tolist())
+  for name in eng.seg_off:
+    o, n = eng.seg_off[name], eng.seg_numel[name]
+    if n == 0:
+      continue
+    a, b = ga[o:o + n], gb[o:o + n]
+    assert torch.isfinite(a).all(), (cfg, name)
+    err = ((a - b).abs().max() / b.abs().max().clamp(min=1e-30)).item()
+    assert err < 2e-5, (cfg, name, err)
+    # post-step weights.  Adam's first step is lr * g / (|g| + 1e-8), i.e. about lr * sign(g): an element whose
+    # gradient is rounding noise (below 1e-3 of the tensor's scale here; seed 534 has one of 1.5e-3 against -3.0e-4 in
+    # a tensor of scale 8.7e4) may legitimately move by +lr on one path and -lr on the other; everywhere else 1e-5
+    pa_, pb_ = pa[o:o + n], pb[o:o + n]
+    solid = b.abs() >= 1e-3 * b.abs().max()
+    pscale = pb_.abs().max().clamp(min=1e-30)
+    if name != "Ws":
+      assert ((pa_ - pb_).abs() * solid).max().item() < 1e-5 * pscale.item(), (cfg, name, "post-step")
+      assert (pa_ - pb_).abs().max().item() <= 2.0 * 1e-3 + 1e-5 * pscale.item(), (cfg, name, "post-step, noise-level gradients")
+    else:   # SGD is linear in the gradient; rows at the threshold are covered by the zero-set check below
+      same = (za == zb).repeat_interleave(eng.spec.H).view(-1)
+      assert ((pa_ - pb_).abs() * same).max().item() < 1e-5 * pscale.item(), (cfg, name, "post-step")
+  # rows within rounding of the threshold may fall either way when the gradients differ in the last bits: at most one
+  assert int((za != zb).sum()) <= 1, (cfg, int((za != zb).sum()))
