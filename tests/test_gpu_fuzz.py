@@ -97,3 +97,40 @@ def test_random_shape_default_path_matches_generic_kernels(seed):
       assert ((pa_ - pb_).abs() * same).max().item() < 1e-5 * pscale.item(), (cfg, name, "post-step")
   # rows within rounding of the threshold may fall either way when the gradients differ in the last bits: at most one
   assert int((za != zb).sum()) <= 1, (cfg, int((za != zb).sum()))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OIVAE_FUZZ_ORACLE_SEEDS", "24"))))
+def test_random_shape_default_path_matches_the_cpu_oracle(seed):
+  """The same drawn shapes against the CPU oracle (oracle/oivae_oracle.py, pinned to the reference by the golden
+  fixtures) run live: scalars 1e-5, gradients 2e-5 of each reference tensor's scale, on the oracle's own initial
+  parameters with a dead group now and then."""
+  from oi_vae_amd import Engine, ModelSpec
+  from oracle import oivae_oracle as O
+  from tests._fixtures import flat_items, rel_err
+  cfg = _draw(seed + 1000)
+  D = sum(cfg["dims"])
+  spec = dict(D=D, K=cfg["K"], H=cfg["H"], M=cfg["M"], gen_type=cfg["gen_type"], group_dims=cfg["dims"])
+  params = O.init_params(spec, seed=seed)
+  if seed % 3 == 0 and len(cfg["dims"]) > 1:
+    params["Ws"][0] = 0.0
+  rng = np.random.default_rng(seed)
+  X = rng.random((cfg["B"], D), dtype=np.float32)
+  eps = rng.standard_normal((cfg["S"], cfg["B"], cfg["K"])).astype(np.float32)
+  tr = O.OracleTrainer(spec, params, lr=1e-3, Ws_lr=1e-4, lam=1.0)
+  info = tr.step(X, eps, c=0.7, prox_step_size=1e-4)
+  eng = Engine(ModelSpec(D=D, K=cfg["K"], H=cfg["H"], M=cfg["M"], group_dims=cfg["dims"], gen_type=cfg["gen_type"]),
+               device="cuda:0")
+  eng.load_params(params)
+  out = eng.forward_backward(X, eps, 0.7)
+  torch.cuda.synchronize()
+  eng.check_errors()
+  sc = out["scalars"].cpu().numpy()
+  for j, k in enumerate(("z_kl", "loglik_term", "logprob_theta", "logprob_W", "loss", "elbo")):
+    assert abs(sc[j] - info[k]) <= 1e-5 * max(abs(info[k]), 1.0), (cfg, k, sc[j], info[k])
+  got = dict(flat_items(eng.export_grads()))
+  # a one-row batch has nothing to average a cancelling K-term dot product's fp32 rounding over: seed 209 (B = 1,
+  # K = 3, H = 1) has a group whose h = z . Ws cancels to 2.3e-5 of its terms, and every gradient that is a multiple
+  # of h differs from the oracle's -- equally fp32 -- value by that much; from a handful of rows on, 2e-5
+  bar = 2e-5 if cfg["B"] * cfg["S"] > 4 else 1e-4
+  for k, b in flat_items(info["grads"]):
+    assert rel_err(got[k], b) < bar, (cfg, k, rel_err(got[k], b))
