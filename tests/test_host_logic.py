@@ -216,3 +216,13 @@ def test_bench_flop_accounting_follows_the_survey():
   rows = bench.GLOBAL_BATCH
   assert abs(bench.decoder_f16_flops(rows) / (bench.decoder_flops_per_row() * rows) - 2.0) < 1e-9
   assert abs((bench.decoder_flops_per_row() + bench.encoder_flops_per_row()) * rows / 1e12 - 7.147) < 0.001
+
+
+def test_c_abi_header_is_plain_c(tmp_path):
+  """include/oivae_hip.h is the boundary a C, C++ or FFI host binds: it must compile as C99 and as C++ on its own."""
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  src = tmp_path / "hdr.c"
+  src.write_text('#include "oivae_hip.h"\nint main(void) { return (int)sizeof(oivae_scalars_t) - 32; }\n')
+  inc = os.path.join(root, "include")
+  subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], check=True)
+  subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)], check=True)
