@@ -79,26 +79,29 @@ def test_scaleup_full_size_against_float64_reference():
         % ({k: "%.1e" % v for k, v in w0.items()}, {k: "%.1e" % v for k, v in w1.items()}))
 
 
-@pytest.mark.parametrize("K,H,M", [(32, 32, 32), (32, 64, 64), (64, 32, 64), (64, 64, 32)])
-def test_padded_32_64_shapes_against_float64_reference(K, H, M):
+@pytest.mark.parametrize("K,H,M,dg", [(32, 32, 32, 64), (32, 64, 64, 64), (64, 32, 64, 64), (64, 64, 32, 64),
+                                      (32, 32, 32, 32), (64, 32, 32, 32)])
+def test_padded_32_64_shapes_against_float64_reference(K, H, M, dg):
   """Generators with a 32-wide latent, group input or hidden layer and 64 outputs per group run the all-64 fp16-term
   kernel on zero-padded copies (csrc/dec_pad64.hip; the encoder GEMMs with 2K = 64 are the fp16-term ones, padded too):
   G = 96 groups, 20000 rows -- ragged, several rounds of second-level accumulation, an odd number of row tiles --
-  against float64 on a state with dead rows and two dead groups, at the full-size test's bars."""
+  against float64 on a state with dead rows and two dead groups, at the full-size test's bars.  D_g = 32 (with
+  H = M = 32): neighbouring groups paired into all-64 virtual groups, one of a pair dead, the other alive."""
   from tests.test_gpu_scale import _engine
   G, B = 96, 20000
-  eng = _engine(G, 64, K, H, M, seed=5)
+  eng = _engine(G, dg, K, H, M, seed=5)
   g = torch.Generator(device="cuda").manual_seed(23)
-  X = torch.rand(B, G * 64, generator=g, device="cuda")
+  X = torch.rand(B, G * dg, generator=g, device="cuda")
   eps = torch.randn(1, B, K, generator=g, device="cuda")
   eng.p["Ws"][torch.rand(G, K, generator=g, device="cuda") < 0.3] = 0.0
   eng.p["Ws"][10:12] = 0.0
-  eng.p["log_sigma"].copy_(torch.log(10 ** (torch.rand(G * 64, generator=g, device="cuda") * 1.5 - 2.5)))
+  eng.p["Ws"][21] = 0.0
+  eng.p["log_sigma"].copy_(torch.log(10 ** (torch.rand(G * dg, generator=g, device="cuda") * 1.5 - 2.5)))
   out = eng.forward_backward(X, eps, 0.8)
   torch.cuda.synchronize()
-  w = _check_against_f64(eng, X, eps, 0.8, out, "padded %d/%d/%d" % (K, H, M), rows_per_chunk=4096)
-  print("\npadded K=%d H=%d M=%d vs float64, worst error / scale per reference tensor: %s"
-        % (K, H, M, {k: "%.1e" % v for k, v in w.items()}))
+  w = _check_against_f64(eng, X, eps, 0.8, out, "padded %d/%d/%d/%d" % (K, H, M, dg), rows_per_chunk=4096)
+  print("\npadded K=%d H=%d M=%d D_g=%d vs float64, worst error / scale per reference tensor: %s"
+        % (K, H, M, dg, {k: "%.1e" % v for k, v in w.items()}))
 
 
 def test_wide_prox_full_size_against_float64_reference():

@@ -86,15 +86,18 @@ def test_mfma_kernels_agree_with_generic_kernels(tmp_path):
       assert err < 2e-5, (other, name, err)
 
 
-@pytest.mark.parametrize("K,H,M,dg", [(k, h, m, d) for k in (32, 64) for h in (32, 64) for m in (32, 64) for d in (32, 64)
-                                      if (k, h, m, d) not in ((64, 64, 64, 64), (32, 32, 32, 32))])
-def test_mixed_32_64_generators_on_the_matrix_decoder(K, H, M, dg):
+@pytest.mark.parametrize("K,H,M,dg,G", [(k, h, m, d, 7) for k in (32, 64) for h in (32, 64) for m in (32, 64) for d in (32, 64)
+                                        if (k, h, m, d) not in ((64, 64, 64, 64), (32, 32, 32, 32))] +
+                                       [(32, 32, 32, 32, 8), (64, 32, 32, 32, 8), (32, 32, 32, 32, 2), (32, 32, 32, 32, 7)])
+def test_mixed_32_64_generators_on_the_matrix_decoder(K, H, M, dg, G):
   """Two-layer generators whose four dimensions are 32 or 64 in any combination take the matrix decoders (dz
   transposed): with 64 outputs per group the all-64 fp16-term kernel on zero-padded copies (csrc/dec_pad64.hip), with
-  32 outputs dec_mfma<K, H, M, DG> on the fp32 matrix instruction.  The shape-generic kernels on the same inputs are the
-  check -- and, for the padded shapes, dec_mfma (OIVAE_DEC=v1) as a third family: ragged row count, two samples,
-  scalars 1e-5, every gradient tensor 2e-5 of its scale."""
-  G, B, S = 7, 150, 2   # 300 rows = 9.4 wave tiles
+  32 outputs dec_mfma<K, H, M, DG> on the fp32 matrix instruction -- except H = M = D_g = 32 with an even number of
+  groups, whose neighbouring groups are PAIRED into all-64 virtual groups for the same kernel (the G = 8 and G = 2
+  cases; G = 7 stays on dec_mfma).  The shape-generic kernels on the same inputs are the check -- and dec_mfma
+  (OIVAE_DEC=v1) as a third family: ragged row count, two samples, scalars 1e-5, every gradient tensor 2e-5 of its
+  scale."""
+  B, S = 150, 2   # 300 rows = 9.4 wave tiles
   lib = _lib.load()
   spec_eng = _engine(G, dg, K, H, M, seed=11)
   import ctypes
@@ -103,7 +106,7 @@ def test_mixed_32_64_generators_on_the_matrix_decoder(K, H, M, dg):
   X = torch.rand(B, G * dg, generator=g, device="cuda")
   eps = torch.randn(S, B, K, generator=g, device="cuda")
   res = []
-  families = [{}, {"OIVAE_FORCE_GENERIC": "1"}] + ([{"OIVAE_DEC": "v1"}] if dg == 64 else [])
+  families = [{}, {"OIVAE_FORCE_GENERIC": "1"}, {"OIVAE_DEC": "v1"}]
   try:
     for env in families:
       _lib.set_test_hooks(**env)

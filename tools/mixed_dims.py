@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Decoder entry point time of two-layer generator shapes with mixed 32/64 dimensions.  Default path: D_g = 64 shapes run
-the all-64 fp16-term kernel on zero-padded copies (csrc/dec_pad64.hip), D_g = 32 shapes dec_mfma<K, H, M, DG> (fp32
-matrix instruction); OIVAE_DEC=v1 forces dec_mfma for every shape, OIVAE_FORCE_GENERIC the shape-generic kernels.
+the all-64 fp16-term kernel on zero-padded copies (csrc/dec_pad64.hip), H = M = D_g = 32 shapes the same kernel on
+PAIRS of groups, the other D_g = 32 shapes dec_mfma<K, H, M, DG> (fp32 matrix instruction); OIVAE_DEC=v1 forces dec_mfma for every shape, OIVAE_FORCE_GENERIC the shape-generic kernels.
 Per shape: ms of the decoder entry point and ms per algorithmic TFLOP (3 G N (2KH + 2HM + 2M D_g)) relative to the
 all-64 shape's.   usage: python tools/mixed_dims.py"""
 import json
@@ -15,7 +15,8 @@ from tests.test_gpu_scale import _engine  # noqa: E402
 
 G, B = 256, 16384
 base = None
-for (K, H, M, dg) in [(64, 64, 64, 64), (32, 64, 64, 64), (64, 32, 64, 64), (64, 64, 32, 64), (32, 32, 32, 64), (64, 32, 64, 32)]:
+for (K, H, M, dg) in [(64, 64, 64, 64), (32, 64, 64, 64), (64, 32, 64, 64), (64, 64, 32, 64), (32, 32, 32, 64), (64, 32, 64, 32),
+                     (32, 32, 32, 32), (64, 32, 32, 32)]:
   g = torch.Generator(device="cuda").manual_seed(1)
   X = torch.rand(B, G * dg, generator=g, device="cuda")
   eps = torch.randn(1, B, K, generator=g, device="cuda")
