@@ -137,6 +137,7 @@ int carve_workspace(const oivae_shape_t& s, int64_t B, int32_t S, void* base, in
   {
     const int64_t pb = plan.mfma ? dec_pad64_bytes(s, N, plan.chunks) : 0;
     w->dec_pad = pb > 0 ? reinterpret_cast<float*>(take(pb)) : nullptr;
+    w->dec_xhalf = 0;
   }
   w->total_bytes = off;
   if (p && bytes < off)

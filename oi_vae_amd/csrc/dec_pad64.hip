@@ -10,13 +10,18 @@
 // rows of the padded [64, N].  Cost: the padded shape's matrix work (K = 32: 1.33x the shape's own flops, M = 32: 2x)
 // at 16x the instruction rate of the fp32 matrix instruction these shapes ran on before (dec_mfma<K, H, M, DG>, still
 // their cross-check: OIVAE_DEC=v1), plus two passes over the parameters (50 MB at G = 1024) and z.
-// D_g = 32 in general is not covered: the kernel reads X in 64-column tiles per group.  One family is, by PAIRING
-// instead of padding: with H = M = D_g = 32 two neighbouring groups g, g + 1 ARE one all-64 group -- group input
+// D_g = 32: the kernel reads X in 64-column tiles per group, and X cannot be padded (17 GB).  Two ways:
+// (a) the OUTPUTS padded: W2[g] [32, M] -> [64, 64] with 32 zero rows (b2: zeros, log_sigma: zeros) and the kernel told
+//     that groups own 32 columns of X (dec_x3_64s<true>: it reads the live columns twice, so every address stays inside
+//     the rows of X, and leaves the padded outputs out of the log-likelihood sum).  A padded output d has mu = 0 and a
+//     residual of its own, but its column of W2^T is zero: nothing of it reaches dt, dz or the live gradients; its own
+//     gradient rows are dropped.  Any G, any K, H, M in {32, 64}: 2x the output product's work.
+// (b) cheaper where it applies, PAIRING: with H = M = D_g = 32 two neighbouring groups g, g + 1 ARE one all-64 group -- group input
 // [Ws_g | Ws_g+1] (K x 64), first layer blockdiag(W1_g, W1_g+1) (64 hidden units, the two groups' side by side), second
 // layer blockdiag(W2_g, W2_g+1) onto the 64 contiguous columns of X the two groups own.  The zero blocks are exact, so
 // every product of the virtual group restricted to its diagonal blocks is the pair's own; its weight gradients hold
 // the pair's in their diagonal blocks (dWs side by side), the off-diagonal blocks are dropped.  G must be even (an odd
-// last group would make the kernel read 32 columns past the rows of X); K = 32 is zero-padded as above.
+// G takes (a)); K = 32 is zero-padded as above.
 #include "common.h"
 
 namespace oivae {
@@ -33,14 +38,19 @@ static bool pair32(const oivae_shape_t& s) {
 
 bool dec_pad64_applies(const oivae_shape_t& s) {
   if (!mfma_decoder_applies(s)) return false;   // two layers, K, H, M, D_g each 32 or 64
-  if (pair32(s)) return true;
-  if (s.uniform_group_dim != 64) return false;
-  return !(s.K == 64 && s.H == 64 && s.M == 64);
+  return !(s.K == 64 && s.H == 64 && s.M == 64 && s.uniform_group_dim == 64);
 }
+// 32 outputs per group padded to 64 ((a) at the head of this file)
+bool dec_pad64_xhalf(const oivae_shape_t& s) {
+  return dec_pad64_applies(s) && s.uniform_group_dim == 32 && !pair32(s);
+}
+enum { kPadZero = 0, kPadPair = 1, kPadXHalf = 2 };
+static int pad_mode(const oivae_shape_t& s) { return pair32(s) ? kPadPair : (s.uniform_group_dim == 32 ? kPadXHalf : kPadZero); }
 
 static oivae_shape_t padded_shape(const oivae_shape_t& s) {
   oivae_shape_t p = s;
   if (pair32(s)) { p.G = s.G / 2; p.uniform_group_dim = 64; p.max_group_dim = 64; }
+  else if (s.uniform_group_dim == 32) { p.D = 64 * s.G; p.uniform_group_dim = 64; p.max_group_dim = 64; }
   p.K = 64; p.H = 64; p.M = 64;
   return p;
 }
@@ -59,7 +69,7 @@ struct PadArgs {
   float *pW1, *pb1, *pW2, *pb2, *pls, *pWs, *pz;     // padded ones
   int64_t nW1, nb1, nW2, nD, nWs, nz;                // element counts of the PADDED arrays (b2 and ls: nD each)
   int K, H, M;
-  int pair;                                          // 1: two 32-wide groups per virtual group (H = M = D_g = 32)
+  int mode;                                          // kPadPair: two 32-wide groups per virtual group; kPadXHalf: 32 outputs per group padded to 64
 };
 
 __global__ __launch_bounds__(256) void pad64_kernel(PadArgs a) {
@@ -68,25 +78,36 @@ __global__ __launch_bounds__(256) void pad64_kernel(PadArgs a) {
   for (int64_t i = tid; i < a.nW1; i += stride) {   // [G][64][64] <- [G][M][H]; pairs: blockdiag(W1_2v, W1_2v+1)
     const int h = (int)(i & 63), m = (int)((i >> 6) & 63);
     const int64_t g = i >> 12;
-    if (a.pair) a.pW1[i] = ((m >> 5) == (h >> 5)) ? a.W1[((2 * g + (m >> 5)) * 32 + (m & 31)) * 32 + (h & 31)] : 0.f;
+    if (a.mode == kPadPair) a.pW1[i] = ((m >> 5) == (h >> 5)) ? a.W1[((2 * g + (m >> 5)) * 32 + (m & 31)) * 32 + (h & 31)] : 0.f;
     else a.pW1[i] = (m < a.M && h < a.H) ? a.W1[(g * a.M + m) * a.H + h] : 0.f;
   }
   for (int64_t i = tid; i < a.nb1; i += stride) {   // [G][64] <- [G][M]; pairs: the two groups' biases side by side
     const int m = (int)(i & 63);
-    if (a.pair) a.pb1[i] = a.b1[i];                 // [Gv][64] = [G][32] element for element
+    if (a.mode == kPadPair) a.pb1[i] = a.b1[i];                 // [Gv][64] = [G][32] element for element
     else a.pb1[i] = (m < a.M) ? a.b1[(i >> 6) * a.M + m] : 0.f;
   }
   for (int64_t i = tid; i < a.nW2; i += stride) {   // [D][64] <- [D][M]; pairs: row d keeps its group's half of the columns
     const int m = (int)(i & 63);
     const int64_t d = i >> 6;
-    if (a.pair) a.pW2[i] = ((m >> 5) == (int)((d >> 5) & 1)) ? a.W2[d * 32 + (m & 31)] : 0.f;
+    if (a.mode == kPadPair) a.pW2[i] = ((m >> 5) == (int)((d >> 5) & 1)) ? a.W2[d * 32 + (m & 31)] : 0.f;
+    else if (a.mode == kPadXHalf) a.pW2[i] = ((d & 32) == 0 && m < a.M) ? a.W2[((d >> 6) * 32 + (d & 31)) * a.M + m] : 0.f;
     else a.pW2[i] = (m < a.M) ? a.W2[d * a.M + m] : 0.f;
   }
-  for (int64_t i = tid; i < a.nD; i += stride) { a.pb2[i] = a.b2[i]; a.pls[i] = a.ls[i]; }
+  for (int64_t i = tid; i < a.nD; i += stride) {
+    if (a.mode == kPadXHalf) {   // virtual output 64 g + r: the group's output r for r < 32
+      const bool live = (i & 32) == 0;
+      const int64_t d = (i >> 6) * 32 + (i & 31);
+      a.pb2[i] = live ? a.b2[d] : 0.f;
+      a.pls[i] = live ? a.ls[d] : 0.f;
+    } else {
+      a.pb2[i] = a.b2[i];
+      a.pls[i] = a.ls[i];
+    }
+  }
   for (int64_t i = tid; i < a.nWs; i += stride) {   // [G][64][64] <- [G][K][H]; pairs: [Ws_2v | Ws_2v+1]
     const int h = (int)(i & 63), k = (int)((i >> 6) & 63);
     const int64_t g = i >> 12;
-    if (a.pair) a.pWs[i] = (k < a.K) ? a.Ws[((2 * g + (h >> 5)) * a.K + k) * 32 + (h & 31)] : 0.f;
+    if (a.mode == kPadPair) a.pWs[i] = (k < a.K) ? a.Ws[((2 * g + (h >> 5)) * a.K + k) * 32 + (h & 31)] : 0.f;
     else a.pWs[i] = (k < a.K && h < a.H) ? a.Ws[(g * a.K + k) * a.H + h] : 0.f;
   }
   for (int64_t i = tid; i < a.nz; i += stride) {    // [N][64] <- [N][K]
@@ -100,7 +121,7 @@ struct UnpadArgs {
   float *W1, *b1, *W2, *b2, *ls, *Ws, *dz;                // the shape's own gradient arrays, dz [K, N]
   int64_t nW1, nb1, nW2, nD, nWs, ndz;                    // element counts of the shape's OWN arrays
   int K, H, M;
-  int pair;
+  int mode;
 };
 
 __global__ __launch_bounds__(256) void unpad64_kernel(UnpadArgs a) {
@@ -111,22 +132,27 @@ __global__ __launch_bounds__(256) void unpad64_kernel(UnpadArgs a) {
     const int64_t r = i / a.H;
     const int m = (int)(r % a.M);
     const int64_t g = r / a.M;
-    if (a.pair) a.W1[i] = a.pW1[((g >> 1) * 64 + 32 * (g & 1) + m) * 64 + 32 * (g & 1) + h];
+    if (a.mode == kPadPair) a.W1[i] = a.pW1[((g >> 1) * 64 + 32 * (g & 1) + m) * 64 + 32 * (g & 1) + h];
     else a.W1[i] = a.pW1[(g * 64 + m) * 64 + h];
   }
-  for (int64_t i = tid; i < a.nb1; i += stride) a.b1[i] = a.pair ? a.pb1[i] : a.pb1[(i / a.M) * 64 + i % a.M];
+  for (int64_t i = tid; i < a.nb1; i += stride) a.b1[i] = (a.mode == kPadPair) ? a.pb1[i] : a.pb1[(i / a.M) * 64 + i % a.M];
   for (int64_t i = tid; i < a.nW2; i += stride) {
     const int64_t d = i / a.M;
     const int m = (int)(i % a.M);
-    a.W2[i] = a.pair ? a.pW2[d * 64 + 32 * ((d >> 5) & 1) + m] : a.pW2[d * 64 + m];
+    const int64_t dv = (a.mode == kPadXHalf) ? (d >> 5) * 64 + (d & 31) : d;   // the virtual output row
+    a.W2[i] = (a.mode == kPadPair) ? a.pW2[d * 64 + 32 * ((d >> 5) & 1) + m] : a.pW2[dv * 64 + m];
   }
-  for (int64_t i = tid; i < a.nD; i += stride) { a.b2[i] = a.pb2[i]; a.ls[i] = a.pls[i]; }
+  for (int64_t i = tid; i < a.nD; i += stride) {
+    const int64_t dv = (a.mode == kPadXHalf) ? (i >> 5) * 64 + (i & 31) : i;
+    a.b2[i] = a.pb2[dv];
+    a.ls[i] = a.pls[dv];
+  }
   for (int64_t i = tid; i < a.nWs; i += stride) {   // [G][K][H] <- [G][64][64]; pairs: the two groups' columns side by side
     const int h = (int)(i % a.H);
     const int64_t r = i / a.H;
     const int k = (int)(r % a.K);
     const int64_t g = r / a.K;
-    if (a.pair) a.Ws[i] = a.pWs[((g >> 1) * 64 + k) * 64 + 32 * (g & 1) + h];
+    if (a.mode == kPadPair) a.Ws[i] = a.pWs[((g >> 1) * 64 + k) * 64 + 32 * (g & 1) + h];
     else a.Ws[i] = a.pWs[(g * 64 + k) * 64 + h];
   }
   for (int64_t i = tid; i < a.ndz; i += stride) a.dz[i] = a.pdz[i];   // the first K rows of [64, N]
@@ -157,8 +183,8 @@ int launch_decoder_pad64(const oivae_shape_t& s, const oivae_tensors_t* params, 
   a.ls = params->log_sigma; a.Ws = params->Ws; a.z = z;
   a.pW1 = p64.gen_W1; a.pb1 = p64.gen_b1; a.pW2 = p64.gen_W2; a.pb2 = p64.gen_b2; a.pls = p64.log_sigma; a.pWs = p64.Ws;
   a.pz = pz;
-  a.nW1 = P.ob1 - P.oW1; a.nb1 = P.oW2 - P.ob1; a.nW2 = P.ob2 - P.oW2; a.nD = s.D; a.nWs = P.total - P.oWs; a.nz = N * 64;
-  a.K = s.K; a.H = s.H; a.M = s.M; a.pair = pair32(s) ? 1 : 0;
+  a.nW1 = P.ob1 - P.oW1; a.nb1 = P.oW2 - P.ob1; a.nW2 = P.ob2 - P.oW2; a.nD = s64.D; a.nWs = P.total - P.oWs; a.nz = N * 64;
+  a.K = s.K; a.H = s.H; a.M = s.M; a.mode = pad_mode(s);
   int64_t most = a.nW1 > a.nz ? a.nW1 : a.nz;
   if (a.nW2 > most) most = a.nW2;
   int64_t blocks = (most + 1023) / 1024;
@@ -173,6 +199,7 @@ int launch_decoder_pad64(const oivae_shape_t& s, const oivae_tensors_t* params, 
   w64.slab = pslab;
   w64.p_dec = P.total;
   w64.dec_pad = nullptr;
+  w64.dec_xhalf = pad_mode(s) == kPadXHalf ? 1 : 0;
   if (int rc = launch_decoder_mfma(s64, &p64, &g64, X, B, S, pz, gen_sig_off, pdz, w64, st)) return rc;
 
   UnpadArgs u;
@@ -182,7 +209,7 @@ int launch_decoder_pad64(const oivae_shape_t& s, const oivae_tensors_t* params, 
   u.Ws = grads->Ws; u.dz = dz;
   u.nW1 = L.ob1 - L.oW1; u.nb1 = L.oW2 - L.ob1; u.nW2 = L.ob2 - L.oW2; u.nD = s.D; u.nWs = L.total - L.oWs;
   u.ndz = N * (int64_t)s.K;
-  u.K = s.K; u.H = s.H; u.M = s.M; u.pair = pair32(s) ? 1 : 0;
+  u.K = s.K; u.H = s.H; u.M = s.M; u.mode = pad_mode(s);
   hipLaunchKernelGGL(unpad64_kernel, dim3((unsigned)blocks), dim3(256), 0, st, u);
   OIVAE_LAUNCH_CHECK();
   return OIVAE_OK;

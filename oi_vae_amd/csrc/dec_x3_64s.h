@@ -55,8 +55,13 @@ __device__ __forceinline__ Frag2 split8_h2v(const f32x4& lo, const f32x4& hi) {
 constexpr int kFlushRounds = 64;   // rounds (two tiles each per weight-gradient wave) between two moves to the second level (32: +0.13 ms at 65536 rows, dead groups 2.4e-6; 64: half of that, 5e-6)
 #define OIVAE_ACC2_ADD(p, v) (void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
+// XH ("X by halves", dec_pad64.hip): the groups own 32 columns of X each, their second layers are zero-padded to 64
+// outputs.  The kernel then reads group g's columns at 32 g, twice (the padded outputs see the live columns again: real
+// values, inside the rows of X; what they produce is dropped), and leaves them out of the log-likelihood sum.
+template <bool XH>
 __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
   constexpr int K = 64, H = 64, M = 64, DG = 64, LW = 65;
+  constexpr int XG = XH ? 32 : 64;   // columns of X per group
   constexpr float kC = 2.885390081777927f;  // 2*log2(e): tanh(x) = 1 - 2/(exp2(kC x) + 1)
   constexpr float kSt = 8192.0f;            // t lies in (-1, 1)
   if (a.gate != nullptr && *a.gate == 0) return;
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
           for (int fb = 0; fb < 4; ++fb)
-            xq[fb][nb] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xrow[nb] + (int64_t)(2 * pairIdx + q) * DG + 16 * fb));
+            xq[fb][nb] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xrow[nb] + (int64_t)(2 * pairIdx + q) * XG + (XH ? 16 * (fb & 1) : 16 * fb)));
         // ---- a1 + b1 in units of 1 / (s1 sz) ----
         f32x4 uT[4][2];
         init_t(uT, sb1);
@@ -750,7 +755,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
       a.gb2[cs + d] = s_gmu;
       a.gls[cs + d] = (nrows - sumq2) * (e * a.inv / sig);
       a.gb1[cs + (int64_t)gq * M + wtid] = s_da1;
-      sred[wtid] = nrows * (-0.5f * kLog2Pi - logf(sig)) - 0.5f * sumq2;
+      sred[wtid] = (XH && wtid >= XG) ? 0.f : nrows * (-0.5f * kLog2Pi - logf(sig)) - 0.5f * sumq2;
     }
     __syncthreads();
     if (worker && wtid < 64) {   // one wave: 64 terms summed in double, in a fixed tree order

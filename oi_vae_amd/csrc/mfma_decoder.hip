@@ -576,7 +576,8 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   const char* dec_env = test_hooks().dec[0] ? test_hooks().dec : nullptr;
   // K, H, M in {32, 64} with 64 outputs per group: the all-64 fp16-term kernel on zero-padded copies (dec_pad64.hip),
   // unless a test hook asks for another family (OIVAE_DEC=v1: dec_mfma<K, H, M, DG> below, their cross-check)
-  if (dec_pad64_applies(s) && w.dec_pad != nullptr && (dec_env == nullptr || dec_env[0] == 's' || dec_env[0] == 'g'))
+  if (dec_pad64_applies(s) && w.dec_pad != nullptr &&
+      (dec_env == nullptr || dec_env[0] == 's' || (dec_env[0] == 'g' && !dec_pad64_xhalf(s))))
     return launch_decoder_pad64(s, params, grads, X, B, S, z, gen_sig_off, dz, w, st);
   const DecLayout L = dec_layout(s);
   const int chunks = w.n_chunks;
@@ -592,7 +593,9 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
     a.gls = grads->log_sigma; a.gWs = grads->Ws;
     a.chunk_stride = 0;
   }
-  a.X = X; a.z = z; a.dzT = dz; a.B = B; a.N = N; a.D = s.D;
+  // (dec_pad64.hip, D_g = 32 padded to 64 outputs: the virtual shape has 64 G rows of parameters, X has 32 G columns)
+  const bool xhalf = w.dec_xhalf != 0;
+  a.X = X; a.z = z; a.dzT = dz; a.B = B; a.N = N; a.D = xhalf ? s.D / 2 : s.D;
   a.inv = 1.0f / ((float)S * (float)B);
   a.sig_off = gen_sig_off;
   a.ll_part = w.ll_part;
@@ -621,6 +624,7 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
   const bool all64 = dec_all64(s);
   const bool use_g = all64 && fits32 && aligned16 && (dec_env == nullptr || dec_env[0] == 'g' || dec_env[0] == 's');
   const bool use_s = use_g && (dec_env == nullptr || dec_env[0] == 's');   // dec_x3_64s: the same kernel on 16x16x32 instructions (default)
+  if (xhalf && !use_s) return fail(OIVAE_E_SHAPE, "MFMA decoder: X by halves is dec_x3_64s's alone");
   uint32_t* rng = w.ranges;
   a.G = s.G;
   a.err = error_words_device();
@@ -644,12 +648,13 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
     a.rng = rng;
     if (use_g) {
       if (use_s)
-        OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_x3_64s),
+        OIVAE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(xhalf ? &dec_x3_64s<true> : &dec_x3_64s<false>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
       const dim3 grid((unsigned)((s.G + 1) / 2), (unsigned)chunks);
       auto run = [&](const MfmaDecArgs& aa) -> int {
         if (!use_s) return launch_xcheck_decoder('g', aa, s.G, chunks, st);
-        hipLaunchKernelGGL(dec_x3_64s, grid, dim3(512), (size_t)kPairLds, st, aa);
+        if (xhalf) hipLaunchKernelGGL(dec_x3_64s<true>, grid, dim3(512), (size_t)kPairLds, st, aa);
+        else hipLaunchKernelGGL(dec_x3_64s<false>, grid, dim3(512), (size_t)kPairLds, st, aa);
         OIVAE_LAUNCH_CHECK();
         return OIVAE_OK;
       };

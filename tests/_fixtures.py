@@ -9,7 +9,7 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 STEP_CONFIGS = ["c1_bars_k8", "c1_bars_k16", "c1_bars_k16_strong", "c2_mocap", "c3_meg_like",
-                "c4_tiny32", "c4_tiny64", "c4_mixed", "c5_wide", "c4_pad32", "c4_pad_m32"]
+                "c4_tiny32", "c4_tiny64", "c4_mixed", "c5_wide", "c4_pad32", "c4_pad_m32", "c4_pad_dg32"]
 
 
 def load(name):

@@ -329,6 +329,11 @@ def main():
              dict(D=128, K=64, H=64, M=32, gen_type="mlp", group_dims=[64] * 2), seed=32,
              steps=[dict(B=64, S=1, c=1.0, t=1e-4)] * 2,
              lr=1e-3, Ws_lr=1e-4, lam=1, prior_rows="1")
+  # 32 outputs per group under 64-wide layers (second layer padded to 64 outputs, X read by halves): odd G, ragged rows
+  run_config("c4_pad_dg32",
+             dict(D=160, K=64, H=64, M=64, gen_type="mlp", group_dims=[32] * 5), seed=33,
+             steps=[dict(B=80, S=1, c=1.0, t=1e-4)] * 2 + [dict(B=33, S=2, c=0.5, t=1e-4)],
+             lr=1e-3, Ws_lr=1e-4, lam=1, prior_rows="1")
   # odd two-layer shapes, S=2
   run_config("c4_mixed",
              dict(D=24, K=16, H=8, M=24, gen_type="mlp", group_dims=[5, 12, 7]), seed=9,

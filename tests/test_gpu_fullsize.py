@@ -80,13 +80,15 @@ def test_scaleup_full_size_against_float64_reference():
 
 
 @pytest.mark.parametrize("K,H,M,dg", [(32, 32, 32, 64), (32, 64, 64, 64), (64, 32, 64, 64), (64, 64, 32, 64),
-                                      (32, 32, 32, 32), (64, 32, 32, 32)])
+                                      (32, 32, 32, 32), (64, 32, 32, 32),
+                                      (64, 64, 64, 32), (32, 64, 32, 32), (64, 32, 64, 32)])
 def test_padded_32_64_shapes_against_float64_reference(K, H, M, dg):
   """Generators with a 32-wide latent, group input or hidden layer and 64 outputs per group run the all-64 fp16-term
   kernel on zero-padded copies (csrc/dec_pad64.hip; the encoder GEMMs with 2K = 64 are the fp16-term ones, padded too):
   G = 96 groups, 20000 rows -- ragged, several rounds of second-level accumulation, an odd number of row tiles --
-  against float64 on a state with dead rows and two dead groups, at the full-size test's bars.  D_g = 32 (with
-  H = M = 32): neighbouring groups paired into all-64 virtual groups, one of a pair dead, the other alive."""
+  against float64 on a state with dead rows and two dead groups, at the full-size test's bars.  D_g = 32 with
+  H = M = 32: neighbouring groups paired into all-64 virtual groups, one of a pair dead, the other alive; D_g = 32
+  otherwise: the second layer padded to 64 outputs, X read by halves."""
   from tests.test_gpu_scale import _engine
   G, B = 96, 20000
   eng = _engine(G, dg, K, H, M, seed=5)

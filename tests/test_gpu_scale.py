@@ -91,12 +91,12 @@ def test_mfma_kernels_agree_with_generic_kernels(tmp_path):
                                        [(32, 32, 32, 32, 8), (64, 32, 32, 32, 8), (32, 32, 32, 32, 2), (32, 32, 32, 32, 7)])
 def test_mixed_32_64_generators_on_the_matrix_decoder(K, H, M, dg, G):
   """Two-layer generators whose four dimensions are 32 or 64 in any combination take the matrix decoders (dz
-  transposed): with 64 outputs per group the all-64 fp16-term kernel on zero-padded copies (csrc/dec_pad64.hip), with
-  32 outputs dec_mfma<K, H, M, DG> on the fp32 matrix instruction -- except H = M = D_g = 32 with an even number of
-  groups, whose neighbouring groups are PAIRED into all-64 virtual groups for the same kernel (the G = 8 and G = 2
-  cases; G = 7 stays on dec_mfma).  The shape-generic kernels on the same inputs are the check -- and dec_mfma
-  (OIVAE_DEC=v1) as a third family: ragged row count, two samples, scalars 1e-5, every gradient tensor 2e-5 of its
-  scale."""
+  transposed) and run the all-64 fp16-term kernel (csrc/dec_pad64.hip): on zero-padded copies with 64 outputs per
+  group; with 32 outputs on copies whose second layer is padded to 64 outputs while the kernel reads X by halves
+  (dec_x3_64s<true>) -- except H = M = D_g = 32 with an even number of groups, whose neighbouring groups are PAIRED
+  into all-64 virtual groups (the G = 8 and G = 2 cases; G = 7 is padded).  The shape-generic kernels on the same
+  inputs are the check -- and dec_mfma<K, H, M, DG> on the fp32 matrix instruction (OIVAE_DEC=v1) as a third family:
+  ragged row count, two samples, scalars 1e-5, every gradient tensor 2e-5 of its scale."""
   B, S = 150, 2   # 300 rows = 9.4 wave tiles
   lib = _lib.load()
   spec_eng = _engine(G, dg, K, H, M, seed=11)

@@ -16,7 +16,7 @@ from tests.test_gpu_scale import _engine  # noqa: E402
 G, B = 256, 16384
 base = None
 for (K, H, M, dg) in [(64, 64, 64, 64), (32, 64, 64, 64), (64, 32, 64, 64), (64, 64, 32, 64), (32, 32, 32, 64), (64, 32, 64, 32),
-                     (32, 32, 32, 32), (64, 32, 32, 32)]:
+                     (32, 32, 32, 32), (64, 32, 32, 32), (64, 64, 64, 32), (32, 64, 32, 32)]:
   g = torch.Generator(device="cuda").manual_seed(1)
   X = torch.rand(B, G * dg, generator=g, device="cuda")
   eps = torch.randn(1, B, K, generator=g, device="cuda")
