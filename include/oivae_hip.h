@@ -186,7 +186,7 @@ int oivae_decoder_fwd_bwd_f32(const oivae_shape_t* shape, const oivae_tensors_t*
 
 /* Layout of the dz buffer that oivae_decoder_fwd_bwd_f32 writes and oivae_encoder_bwd_f32 reads, for these
  * shapes and N = S*B rows: 0 = [N, K] row-major (sample-major rows), 1 = TRANSPOSED [K, N] (the matrix-core
- * decoders: two-layer generators whose K, H, M, D_g are each 32 or 64), negative = error.  Both entry points derive it the same way
+ * decoders: two-layer generators up to 64 wide with one output width, when the padded launch pays at this B, S), negative = error.  Both entry points derive it the same way
  * from (shape, B, S) and the library's test hooks (below); a host that reads dz, or feeds its own, asks here.
  * dz is summed over the groups with float atomics by every decoder kernel except the flat (many-small-groups)
  * path, so it -- and the encoder gradients computed from it -- can differ in the last bits from run to run

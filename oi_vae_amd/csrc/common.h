@@ -67,7 +67,7 @@ struct Workspace {
   char*   small;                           // small_step.hip: per-block gradient slabs, KL / log-lik partials, ticket counter
   float*  dec_acc2;                        // dec_x3_64s: second-level slabs of its weight-gradient waves (nullptr: not needed)
   float*  dec_pad;                         // dec_pad64.hip: zero-padded parameters, gradients, slabs, z and dz of the {32,64} mixes (nullptr: other shapes)
-  int32_t dec_xhalf;                       // dec_pad64.hip's virtual launch for D_g = 32: X has 32 columns per group (0 everywhere else)
+  int32_t dec_xhalf;                       // dec_pad64.hip's virtual launch for D_g < 64: the columns of X per group (0 everywhere else)
   int64_t total_bytes;
 };
 
@@ -116,7 +116,11 @@ int64_t mfma_decoder_acc2_bytes(const oivae_shape_t& s, int64_t N, int chunks); 
 // dec_pad64.hip: K, H, M in {32, 64} (not all 64) with 64 outputs per group run through the all-64 fp16-term kernel on
 // zero-padded copies
 bool dec_pad64_applies(const oivae_shape_t& s);
-bool dec_pad64_xhalf(const oivae_shape_t& s);   // ... with 32 outputs per group padded to 64 (dec_x3_64s<true> only)
+bool dec_pad64_xhalf(const oivae_shape_t& s);   // ... with fewer than 64 outputs per group padded to 64 (dec_x3_64s<true> only)
+// shapes outside {32, 64}^4 take the padded launch from this much per-group work on, K H + H M + M D_g (all-64: 12288),
+// or from this many (row, group) pairs on (mfma_decoder_pays, mfma_decoder.hip)
+constexpr int kPadMinWork = 1536;
+constexpr int64_t kPadMinRowGroups = 524288;
 int64_t dec_pad64_bytes(const oivae_shape_t& s, int64_t N, int chunks);
 int launch_decoder_pad64(const oivae_shape_t& s, const oivae_tensors_t* params, const oivae_tensors_t* grads,
                          const float* X, int64_t B, int32_t S, const float* z, float gen_sig_off, float* dz,

@@ -1,8 +1,9 @@
-// Two-layer generators with K, H, M in {32, 64} (not all 64) and 64 outputs per group on the fp16-term decoder.
+// Two-layer generators up to 64 wide (K, H, M <= 64, one output width D_g <= 64 for all groups; not all 64) on the
+// fp16-term decoder.
 //
 // dec_x3_64s (dec_x3_64s.h) is written for K = H = M = D_g = 64: its LDS plan, operand fragments and register
-// allocation are fixed to that shape.  A generator whose latent, group-input or hidden width is 32 is the same
-// computation with half of some operand rows equal to zero, and zeros are exact in every term of the split arithmetic
+// allocation are fixed to that shape.  A generator whose latent, group-input or hidden width is narrower is the same
+// computation with some operand rows equal to zero, and zeros are exact in every term of the split arithmetic
 // (x3_split.h) -- so these shapes run through that kernel on ZERO-PADDED copies of the parameters and of z:
 //   Ws[g] [K, H] -> [64, 64],  W1[g] [M, H] -> [64, 64],  b1[g] [M] -> [64],  W2 [D, M] -> [D, 64],  z [N, K] -> [N, 64]
 // (a padded hidden unit has a1 = 0, t = tanh 0 = 0 and a zero column in W2; a padded latent has z = 0 and a zero row in
@@ -11,11 +12,11 @@
 // at 16x the instruction rate of the fp32 matrix instruction these shapes ran on before (dec_mfma<K, H, M, DG>, still
 // their cross-check: OIVAE_DEC=v1), plus two passes over the parameters (50 MB at G = 1024) and z.
 // D_g = 32: the kernel reads X in 64-column tiles per group, and X cannot be padded (17 GB).  Two ways:
-// (a) the OUTPUTS padded: W2[g] [32, M] -> [64, 64] with 32 zero rows (b2: zeros, log_sigma: zeros) and the kernel told
-//     that groups own 32 columns of X (dec_x3_64s<true>: it reads the live columns twice, so every address stays inside
-//     the rows of X, and leaves the padded outputs out of the log-likelihood sum).  A padded output d has mu = 0 and a
+// (a) the OUTPUTS padded: W2[g] [D_g, M] -> [64, 64] with zero rows (b2: zeros, log_sigma: zeros) and the kernel told
+//     that groups own D_g columns of X (dec_x3_64s<true>: the padded outputs' lanes read the group's first columns
+//     again, so every address stays inside the rows of X, and the padded outputs stay out of the log-likelihood sum).  A padded output d has mu = 0 and a
 //     residual of its own, but its column of W2^T is zero: nothing of it reaches dt, dz or the live gradients; its own
-//     gradient rows are dropped.  Any G, any K, H, M in {32, 64}: 2x the output product's work.
+//     gradient rows are dropped.  Any G, any K, H, M, any D_g that is a multiple of 4 (X is read 16 bytes per lane).
 // (b) cheaper where it applies, PAIRING: with H = M = D_g = 32 two neighbouring groups g, g + 1 ARE one all-64 group -- group input
 // [Ws_g | Ws_g+1] (K x 64), first layer blockdiag(W1_g, W1_g+1) (64 hidden units, the two groups' side by side), second
 // layer blockdiag(W2_g, W2_g+1) onto the 64 contiguous columns of X the two groups own.  The zero blocks are exact, so
@@ -37,20 +38,20 @@ static bool pair32(const oivae_shape_t& s) {
 }
 
 bool dec_pad64_applies(const oivae_shape_t& s) {
-  if (!mfma_decoder_applies(s)) return false;   // two layers, K, H, M, D_g each 32 or 64
+  if (!mfma_decoder_applies(s)) return false;   // two layers, K, H, M, D_g <= 64, D_g uniform and a multiple of 4
   return !(s.K == 64 && s.H == 64 && s.M == 64 && s.uniform_group_dim == 64);
 }
 // 32 outputs per group padded to 64 ((a) at the head of this file)
 bool dec_pad64_xhalf(const oivae_shape_t& s) {
-  return dec_pad64_applies(s) && s.uniform_group_dim == 32 && !pair32(s);
+  return dec_pad64_applies(s) && s.uniform_group_dim != 64 && !pair32(s);
 }
 enum { kPadZero = 0, kPadPair = 1, kPadXHalf = 2 };
-static int pad_mode(const oivae_shape_t& s) { return pair32(s) ? kPadPair : (s.uniform_group_dim == 32 ? kPadXHalf : kPadZero); }
+static int pad_mode(const oivae_shape_t& s) { return pair32(s) ? kPadPair : (s.uniform_group_dim != 64 ? kPadXHalf : kPadZero); }
 
 static oivae_shape_t padded_shape(const oivae_shape_t& s) {
   oivae_shape_t p = s;
   if (pair32(s)) { p.G = s.G / 2; p.uniform_group_dim = 64; p.max_group_dim = 64; }
-  else if (s.uniform_group_dim == 32) { p.D = 64 * s.G; p.uniform_group_dim = 64; p.max_group_dim = 64; }
+  else if (s.uniform_group_dim != 64) { p.D = 64 * s.G; p.uniform_group_dim = 64; p.max_group_dim = 64; }
   p.K = 64; p.H = 64; p.M = 64;
   return p;
 }
@@ -69,7 +70,8 @@ struct PadArgs {
   float *pW1, *pb1, *pW2, *pb2, *pls, *pWs, *pz;     // padded ones
   int64_t nW1, nb1, nW2, nD, nWs, nz;                // element counts of the PADDED arrays (b2 and ls: nD each)
   int K, H, M;
-  int mode;                                          // kPadPair: two 32-wide groups per virtual group; kPadXHalf: 32 outputs per group padded to 64
+  int mode;                                          // kPadPair: two 32-wide groups per virtual group; kPadXHalf: xg < 64 outputs per group padded to 64
+  int xg;
 };
 
 __global__ __launch_bounds__(256) void pad64_kernel(PadArgs a) {
@@ -90,13 +92,13 @@ __global__ __launch_bounds__(256) void pad64_kernel(PadArgs a) {
     const int m = (int)(i & 63);
     const int64_t d = i >> 6;
     if (a.mode == kPadPair) a.pW2[i] = ((m >> 5) == (int)((d >> 5) & 1)) ? a.W2[d * 32 + (m & 31)] : 0.f;
-    else if (a.mode == kPadXHalf) a.pW2[i] = ((d & 32) == 0 && m < a.M) ? a.W2[((d >> 6) * 32 + (d & 31)) * a.M + m] : 0.f;
+    else if (a.mode == kPadXHalf) a.pW2[i] = ((int)(d & 63) < a.xg && m < a.M) ? a.W2[((d >> 6) * a.xg + (d & 63)) * a.M + m] : 0.f;
     else a.pW2[i] = (m < a.M) ? a.W2[d * a.M + m] : 0.f;
   }
   for (int64_t i = tid; i < a.nD; i += stride) {
-    if (a.mode == kPadXHalf) {   // virtual output 64 g + r: the group's output r for r < 32
-      const bool live = (i & 32) == 0;
-      const int64_t d = (i >> 6) * 32 + (i & 31);
+    if (a.mode == kPadXHalf) {   // virtual output 64 g + r: the group's output r for r < xg
+      const bool live = (int)(i & 63) < a.xg;
+      const int64_t d = live ? (i >> 6) * a.xg + (i & 63) : 0;
       a.pb2[i] = live ? a.b2[d] : 0.f;
       a.pls[i] = live ? a.ls[d] : 0.f;
     } else {
@@ -122,6 +124,7 @@ struct UnpadArgs {
   int64_t nW1, nb1, nW2, nD, nWs, ndz;                    // element counts of the shape's OWN arrays
   int K, H, M;
   int mode;
+  int xg;
 };
 
 __global__ __launch_bounds__(256) void unpad64_kernel(UnpadArgs a) {
@@ -139,11 +142,11 @@ __global__ __launch_bounds__(256) void unpad64_kernel(UnpadArgs a) {
   for (int64_t i = tid; i < a.nW2; i += stride) {
     const int64_t d = i / a.M;
     const int m = (int)(i % a.M);
-    const int64_t dv = (a.mode == kPadXHalf) ? (d >> 5) * 64 + (d & 31) : d;   // the virtual output row
+    const int64_t dv = (a.mode == kPadXHalf) ? (d / a.xg) * 64 + d % a.xg : d;   // the virtual output row
     a.W2[i] = (a.mode == kPadPair) ? a.pW2[d * 64 + 32 * ((d >> 5) & 1) + m] : a.pW2[dv * 64 + m];
   }
   for (int64_t i = tid; i < a.nD; i += stride) {
-    const int64_t dv = (a.mode == kPadXHalf) ? (i >> 5) * 64 + (i & 31) : i;
+    const int64_t dv = (a.mode == kPadXHalf) ? (i / a.xg) * 64 + i % a.xg : i;
     a.b2[i] = a.pb2[dv];
     a.ls[i] = a.pls[dv];
   }
@@ -184,7 +187,7 @@ int launch_decoder_pad64(const oivae_shape_t& s, const oivae_tensors_t* params, 
   a.pW1 = p64.gen_W1; a.pb1 = p64.gen_b1; a.pW2 = p64.gen_W2; a.pb2 = p64.gen_b2; a.pls = p64.log_sigma; a.pWs = p64.Ws;
   a.pz = pz;
   a.nW1 = P.ob1 - P.oW1; a.nb1 = P.oW2 - P.ob1; a.nW2 = P.ob2 - P.oW2; a.nD = s64.D; a.nWs = P.total - P.oWs; a.nz = N * 64;
-  a.K = s.K; a.H = s.H; a.M = s.M; a.mode = pad_mode(s);
+  a.K = s.K; a.H = s.H; a.M = s.M; a.mode = pad_mode(s); a.xg = s.uniform_group_dim;
   int64_t most = a.nW1 > a.nz ? a.nW1 : a.nz;
   if (a.nW2 > most) most = a.nW2;
   int64_t blocks = (most + 1023) / 1024;
@@ -199,7 +202,7 @@ int launch_decoder_pad64(const oivae_shape_t& s, const oivae_tensors_t* params, 
   w64.slab = pslab;
   w64.p_dec = P.total;
   w64.dec_pad = nullptr;
-  w64.dec_xhalf = pad_mode(s) == kPadXHalf ? 1 : 0;
+  w64.dec_xhalf = pad_mode(s) == kPadXHalf ? s.uniform_group_dim : 0;
   if (int rc = launch_decoder_mfma(s64, &p64, &g64, X, B, S, pz, gen_sig_off, pdz, w64, st)) return rc;
 
   UnpadArgs u;
@@ -209,7 +212,7 @@ int launch_decoder_pad64(const oivae_shape_t& s, const oivae_tensors_t* params, 
   u.Ws = grads->Ws; u.dz = dz;
   u.nW1 = L.ob1 - L.oW1; u.nb1 = L.oW2 - L.ob1; u.nW2 = L.ob2 - L.oW2; u.nD = s.D; u.nWs = L.total - L.oWs;
   u.ndz = N * (int64_t)s.K;
-  u.K = s.K; u.H = s.H; u.M = s.M; u.mode = pad_mode(s);
+  u.K = s.K; u.H = s.H; u.M = s.M; u.mode = pad_mode(s); u.xg = s.uniform_group_dim;
   hipLaunchKernelGGL(unpad64_kernel, dim3((unsigned)blocks), dim3(256), 0, st, u);
   OIVAE_LAUNCH_CHECK();
   return OIVAE_OK;

@@ -35,6 +35,7 @@ struct MfmaDecArgs {
   ErrWords err;          // the library's error words (host-mapped + device-resident), raised by a timed-out LDS wait
   int G;
   float* acc2;           // dec_x3_64s: second-level slabs of the weight-gradient waves (nullptr: short launches, no second level)
+  int xg;                // dec_x3_64s<true>: columns of X per group (< 64, a multiple of 4); 0 otherwise
 };
 
 __device__ __forceinline__ float fast_tanh(float x) {

@@ -55,13 +55,14 @@ __device__ __forceinline__ Frag2 split8_h2v(const f32x4& lo, const f32x4& hi) {
 constexpr int kFlushRounds = 64;   // rounds (two tiles each per weight-gradient wave) between two moves to the second level (32: +0.13 ms at 65536 rows, dead groups 2.4e-6; 64: half of that, 5e-6)
 #define OIVAE_ACC2_ADD(p, v) (void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
-// XH ("X by halves", dec_pad64.hip): the groups own 32 columns of X each, their second layers are zero-padded to 64
-// outputs.  The kernel then reads group g's columns at 32 g, twice (the padded outputs see the live columns again: real
-// values, inside the rows of X; what they produce is dropped), and leaves them out of the log-likelihood sum.
+// XH (dec_pad64.hip): the groups own a.xg < 64 columns of X each (a multiple of 4), their second layers are zero-padded
+// to 64 outputs.  The kernel then reads group g's columns at g * a.xg; the lanes of the padded outputs read the
+// group's first columns again (real values, inside the rows of X; what they produce is dropped), and the padded
+// outputs stay out of the log-likelihood sum.
 template <bool XH>
 __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
   constexpr int K = 64, H = 64, M = 64, DG = 64, LW = 65;
-  constexpr int XG = XH ? 32 : 64;   // columns of X per group
+  const int XG = XH ? a.xg : 64;   // columns of X per group
   constexpr float kC = 2.885390081777927f;  // 2*log2(e): tanh(x) = 1 - 2/(exp2(kC x) + 1)
   constexpr float kSt = 8192.0f;            // t lies in (-1, 1)
   if (a.gate != nullptr && *a.gate == 0) return;
@@ -364,6 +365,11 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
     };
     char* const dzb = reinterpret_cast<char*>(a.dzT);
     const int64_t rowbytes = a.N * 4;
+    int xoffs[4] = {0, 0, 0, 0};   // XH: this lane's four columns inside a group (the padded outputs' lanes: the first columns)
+    if (XH) {
+#pragma unroll
+      for (int fb = 0; fb < 4; ++fb) xoffs[fb] = (16 * fb + 4 * lq < XG) ? 16 * fb + 4 * lq : 0;
+    }
     Frag2 zf[4];
     {
       int t1 = tile_of(0, sw);
@@ -384,8 +390,8 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
       const int nT0 = live0 ? r0 + lc : N32 - 1, nT1 = live1 ? r0 + 16 + lc : N32 - 1;
       const float liveT[2] = {live0 ? 1.0f : 0.0f, live1 ? 1.0f : 0.0f};
       const float* xrow[2];
-      xrow[0] = a.X + (one_sample ? (int64_t)nT0 : (int64_t)nT0 % a.B) * (int64_t)a.D + 4 * lq;
-      xrow[1] = a.X + (one_sample ? (int64_t)nT1 : (int64_t)nT1 % a.B) * (int64_t)a.D + 4 * lq;
+      xrow[0] = a.X + (one_sample ? (int64_t)nT0 : (int64_t)nT0 % a.B) * (int64_t)a.D + (XH ? 0 : 4 * lq);
+      xrow[1] = a.X + (one_sample ? (int64_t)nT1 : (int64_t)nT1 % a.B) * (int64_t)a.D + (XH ? 0 : 4 * lq);
       f32x4 dz[4][2];
 #pragma unroll
       for (int fb = 0; fb < 4; ++fb) { dz[fb][0] = (f32x4)(0.f); dz[fb][1] = (f32x4)(0.f); }
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(512, 1) void dec_x3_64s(MfmaDecArgs a) {
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
           for (int fb = 0; fb < 4; ++fb)
-            xq[fb][nb] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xrow[nb] + (int64_t)(2 * pairIdx + q) * XG + (XH ? 16 * (fb & 1) : 16 * fb)));
+            xq[fb][nb] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xrow[nb] + (int64_t)(2 * pairIdx + q) * XG + (XH ? xoffs[fb] : 16 * fb)));
         // ---- a1 + b1 in units of 1 / (s1 sz) ----
         f32x4 uT[4][2];
         init_t(uT, sb1);

@@ -772,6 +772,7 @@ static int64_t dec_lds_floats(const oivae_shape_t& s, int R, int DC) {
 }
 
 bool mfma_decoder_applies(const oivae_shape_t& s);          // mfma_decoder.hip
+bool mfma_decoder_pays(const oivae_shape_t& s, int64_t N);  // mfma_decoder.hip
 int mfma_decoder_chunks(const oivae_shape_t& s, int64_t N);  // mfma_decoder.hip
 bool mfma_encoder_applies(const oivae_shape_t& s);           // mfma_encoder.hip
 int launch_encoder_fwd_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, const float* X, int64_t B,
@@ -781,7 +782,7 @@ int launch_encoder_bwd_mfma(const oivae_shape_t& s, const oivae_tensors_t* grads
 
 DecPlan plan_decoder(const oivae_shape_t& s, int64_t N) {
   DecPlan pl;
-  pl.mfma = mfma_decoder_applies(s);
+  pl.mfma = mfma_decoder_applies(s) && mfma_decoder_pays(s, N);
   pl.flat = !pl.mfma && flat_decoder_applies(s, N);
   pl.single = !pl.mfma && !pl.flat && single_decoder_applies(s);
   pl.DC = s.max_group_dim < 64 ? s.max_group_dim : 64;

@@ -520,12 +520,22 @@ __global__ __launch_bounds__(256) void gated_zero_f32(float* __restrict__ p, int
 bool mfma_decoder_applies(const oivae_shape_t& s) {
   if (test_hooks().force_generic) return false;  // test hook: cross-check the two kernel families
   if (s.gen_type != OIVAE_GEN_MLP) return false;
-  // every dimension 32 or 64, one output width for all groups: the all-64 shape has its own kernels (dec_x3_64s and
-  // its cross-checks), the fifteen other combinations run the dimension-generic dec_mfma<K, H, M, DG> on the fp32
-  // matrix instruction
+  // Two-layer generators no wider than 64 anywhere, one output width for all groups (a multiple of 4: X is read 16
+  // bytes per lane): the all-64 shape has its own kernels (dec_x3_64s and its cross-checks), every other one runs
+  // dec_x3_64s on zero-padded or pair-packed copies (dec_pad64.hip; dec_mfma<K, H, M, DG> on the fp32 matrix instruction
+  // is the cross-check where every dimension is 32 or 64).
+  const int dg = s.uniform_group_dim;
+  return s.K >= 1 && s.K <= 64 && s.H >= 1 && s.H <= 64 && s.M >= 1 && s.M <= 64 && dg >= 4 && dg <= 64 && (dg & 3) == 0;
+}
+// ... and whether it pays: a padded launch costs what the all-64 shape costs whatever it holds (0.06 ms + 0.18 us per
+// 1024 row-groups), the shape-generic kernel's time follows the shape's own work.  tools/narrow_dims.py: at 4.2 M
+// row-groups the padded launch wins for every shape tried (0.75 ms against 1.05 ms at K = H = M = D_g = 8, 75 ms at
+// 64/64/64/48); at 2048 row-groups from K H + H M + M D_g of about 1500 on.  Shapes of 32s and 64s always take it.
+bool mfma_decoder_pays(const oivae_shape_t& s, int64_t N) {
   const int dg = s.uniform_group_dim;
   auto ok = [](int v) { return v == 32 || v == 64; };
-  return ok(s.K) && ok(s.H) && ok(s.M) && ok(dg);
+  if (ok(s.K) && ok(s.H) && ok(s.M) && ok(dg)) return true;
+  return s.K * s.H + s.H * s.M + s.M * dg >= kPadMinWork || N * (int64_t)s.G >= kPadMinRowGroups;
 }
 static inline bool dec_all64(const oivae_shape_t& s) {
   return s.K == 64 && s.H == 64 && s.M == 64 && s.uniform_group_dim == 64;
@@ -593,9 +603,10 @@ int launch_decoder_mfma(const oivae_shape_t& s, const oivae_tensors_t* params, c
     a.gls = grads->log_sigma; a.gWs = grads->Ws;
     a.chunk_stride = 0;
   }
-  // (dec_pad64.hip, D_g = 32 padded to 64 outputs: the virtual shape has 64 G rows of parameters, X has 32 G columns)
+  // (dec_pad64.hip, D_g < 64 padded to 64 outputs: the virtual shape has 64 G rows of parameters, X has D_g G columns)
   const bool xhalf = w.dec_xhalf != 0;
-  a.X = X; a.z = z; a.dzT = dz; a.B = B; a.N = N; a.D = xhalf ? s.D / 2 : s.D;
+  a.X = X; a.z = z; a.dzT = dz; a.B = B; a.N = N; a.D = xhalf ? s.G * w.dec_xhalf : s.D;
+  a.xg = w.dec_xhalf;
   a.inv = 1.0f / ((float)S * (float)B);
   a.sig_off = gen_sig_off;
   a.ll_part = w.ll_part;

@@ -81,7 +81,8 @@ def test_scaleup_full_size_against_float64_reference():
 
 @pytest.mark.parametrize("K,H,M,dg", [(32, 32, 32, 64), (32, 64, 64, 64), (64, 32, 64, 64), (64, 64, 32, 64),
                                       (32, 32, 32, 32), (64, 32, 32, 32),
-                                      (64, 64, 64, 32), (32, 64, 32, 32), (64, 32, 64, 32)])
+                                      (64, 64, 64, 32), (32, 64, 32, 32), (64, 32, 64, 32),
+                                      (40, 24, 56, 44), (10, 8, 24, 64)])
 def test_padded_32_64_shapes_against_float64_reference(K, H, M, dg):
   """Generators with a 32-wide latent, group input or hidden layer and 64 outputs per group run the all-64 fp16-term
   kernel on zero-padded copies (csrc/dec_pad64.hip; the encoder GEMMs with 2K = 64 are the fp16-term ones, padded too):

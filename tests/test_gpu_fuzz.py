@@ -1,5 +1,5 @@
 """Seeded random shapes through the default kernel choice and through the shape-generic kernels (OIVAE_FORCE_GENERIC):
-whatever path a shape is served by -- fp16-term or fp32 matrix decoders, padded 32/64 mixes, dec_single, the flat
+whatever path a shape is served by -- fp16-term or fp32 matrix decoders, padded / paired launches of narrower two-layer shapes, dec_single, the flat
 many-small-groups path, h2 / fp32 / generic encoder GEMMs, ragged groups, batches that are no multiple of anything --
 one step must give the same scalars (1e-5) and gradients (2e-5 of each tensor's scale), and the optimizers + proximal
 step the same zero set.  The shapes are drawn, not chosen: the point is the combinations nobody wrote a test for."""
@@ -19,10 +19,15 @@ def _draw(seed):
   kind = r.choice(["linear", "tanh_linear", "mlp", "mlp_mix", "small_groups"])
   S = int(r.choice([1, 1, 2, 3]))
   B = int(r.choice([1, 7, 33, 64, 100, 257]))
-  if kind == "mlp_mix":      # the matrix decoders' shapes: every dimension 32 or 64
+  if kind == "mlp_mix":      # the matrix decoders' shapes: every dimension 32 or 64 ...
     K, H, M = (int(r.choice([32, 64])) for _ in range(3))
     dg = int(r.choice([32, 64]))
     G = int(r.integers(1, 6))
+    if r.random() < 0.5:     # ... or any width up to 64 with enough work per group for the padded launch (kPadMinWork)
+      for _ in range(100):
+        K, H, M, dg = int(r.integers(1, 65)), int(r.integers(1, 65)), int(r.integers(1, 65)), 4 * int(r.integers(1, 17))
+        if K * H + H * M + M * dg >= 1536:
+          break
     return dict(gen_type="mlp", K=K, H=H, M=M, dims=[dg] * G, B=B, S=S)
   if kind == "small_groups":   # towards the flat path: K a multiple of 128, G H a multiple of 128, uniform tiny groups
     H = int(r.choice([4, 8]))
