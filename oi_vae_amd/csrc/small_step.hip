@@ -18,6 +18,7 @@
 // Built with -ffp-contract=off like prox.hip (the proximal step's arithmetic is pinned); products that may fuse are
 // written as fmaf.
 #include "common.h"
+#include <stdlib.h>
 #include "prox_dev.h"
 
 namespace oivae {
@@ -44,9 +45,13 @@ SmallPlan plan_small_step(const oivae_shape_t& s, int64_t B, int32_t S) {
   const int64_t P = small_param_count(s);
   if (P > kSmallMaxParams) return p;
   // few, fat workgroups: the step is latency-bound (a handful of dependent phases), and the last workgroup adds one
-  // slab per workgroup -- about 48 decoder rows each, one (row, group) item per thread in the decoder phase
+  // slab per workgroup -- about 30 decoder rows each, one (row, group) item per thread in the decoder phase
   const int64_t N = B * (int64_t)S;
-  int nb = (int)((N + 47) / 48);   // (24, 48, 96, 192 rows tried: bars 35 / 34 / 40 / 44 us per step, mocap 61 / 59 / 79 / 99)
+  // (rows per workgroup tried, us per step -- round 2: 24 / 48 / 96 / 192 rows: bars 35 / 34 / 40 / 44, mocap 61 / 59 / 79 / 99;
+  // round 3, outputs indexed by kind and loads batched: 24 / 30 / 40 / 48: bars 30.5 / 30.5 / 31.1 / 31.9, mocap 46.3 / 46.3 /
+  // 46.4 / 48.4: at 30 mocap's 29 groups are one decoder round)
+  int nb = (int)((N + 29) / 30);
+  if (nb > kSmallMaxBlocks) nb = kSmallMaxBlocks;   // larger batches: fatter workgroups, as far as LDS goes (checked below)
   if (nb < 1) nb = 1;
   int RB = (int)((B + nb - 1) / nb);
   if (RB * S > kSmallThreads) RB = kSmallThreads / S;
@@ -178,14 +183,31 @@ __global__ __launch_bounds__(kSmallThreads) void small_step_kernel(SmallArgs a) 
 
   OIVAE_STAMP(0);
   // ---- X rows of this workgroup (rows past the batch read as zeros and are masked everywhere below) ----
-  for (int o = tid; o < RB * D; o += kSmallThreads) {
-    const int r = o / D, d = o - r * D;
-    Xs[r * DP + d] = (r0 + r < B) ? a.X[(r0 + r) * D + d] : 0.f;
+  // (four loads in flight per thread and loop: a pass of this kernel costs one trip to memory whatever it moves)
+  for (int o0 = tid; o0 < RB * D; o0 += 4 * kSmallThreads) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int o = o0 + u * kSmallThreads, r = o / D, d = o - r * D;
+      v[u] = (o < RB * D && r0 + r < B) ? a.X[(r0 + r) * D + d] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int o = o0 + u * kSmallThreads, r = o / D, d = o - r * D;
+      if (o < RB * D) Xs[r * DP + d] = v[u];
+    }
   }
   for (int o = tid; o < NR * KP; o += kSmallThreads) dzs[o] = 0.f;
-  for (int i = tid; i < P32; i += kSmallThreads) {   // every parameter into LDS, packed in the slab's order
-    const int q = OIVAE_SEG(i);
-    Ps[i] = a.P0[OIVAE_FOFF(q) + i - OIVAE_OFF(q)];
+  for (int i0 = tid; i0 < P32; i0 += 4 * kSmallThreads) {   // every parameter into LDS, packed in the slab's order
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * kSmallThreads, q = OIVAE_SEG(i);
+      v[u] = (i < P32) ? a.P0[OIVAE_FOFF(q) + i - OIVAE_OFF(q)] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * kSmallThreads < P32) Ps[i0 + u * kSmallThreads] = v[u];
   }
   __syncthreads();
   // ---- encoder forward: pre[r][j] = b_j + sum_d X[r][d] W[j][d], j < K the mu head, j >= K the sigma head ----
@@ -272,10 +294,12 @@ __global__ __launch_bounds__(kSmallThreads) void small_step_kernel(SmallArgs a) 
     if (g0 == 0) OIVAE_STAMP(9);
     // outputs of the round: per group K H of dWs, dg H of dW2, dg of db2, dg of dlog_sigma -- sums over the NR rows --
     // and this round's share of dz, [NR][K]: sums over the round's groups and hidden units, in a fixed order
-    const int cmax = K * H + DGS * H + 2 * DGS;
-    for (int o = tid; o < gcur * cmax + NR * K; o += kSmallThreads) {
-      if (o >= gcur * cmax) {
-        const int e = o - gcur * cmax, k = e / NR, n = e - k * NR;   // lanes walk the rows
+    // (indexed by KIND first -- all groups' dWs, then dW2, db2, dlog_sigma, dz --: the kinds are different loops, and a
+    // wave whose lanes hold several kinds runs them one after the other; by group first every wave held all of them)
+    const int t1 = gcur * K * H, t2 = t1 + gcur * DGS * H, t3 = t2 + gcur * DGS, t4 = t3 + gcur * DGS;
+    for (int o = tid; o < t4 + NR * K; o += kSmallThreads) {
+      if (o >= t4) {
+        const int e = o - t4, k = e / NR, n = e - k * NR;   // lanes walk the rows
         float sacc = dzs[n * KP + k];
         for (int gi = 0; gi < gcur; ++gi) {
           const float* Wr = pWs + ((g0 + gi) * K + k) * H;
@@ -286,31 +310,35 @@ __global__ __launch_bounds__(kSmallThreads) void small_step_kernel(SmallArgs a) 
         dzs[n * KP + k] = sacc;
         continue;
       }
-      const int gi = o / cmax, idx = o - gi * cmax, g = g0 + gi;
-      const int o0 = a.group_off[g], dg = a.group_off[g + 1] - o0;
-      const int base = gi * NR;
       float sacc = 0.f;
-      if (idx < K * H) {
-        const int k = idx / H, hh = idx - k * H;
-        #pragma unroll 8
+      if (o < t1) {
+        const int gi = o / (K * H), idx = o - gi * (K * H), k = idx / H, hh = idx - k * H, base = gi * NR;
+#pragma unroll 8
         for (int n = 0; n < NR; ++n) sacc = __builtin_fmaf(zs[n * KP + k], dHS[(base + n) * HP + hh], sacc);
-        slab[oWs + (g * K + k) * H + hh] = sacc;
-      } else if (idx < K * H + DGS * H) {
-        const int e = idx - K * H, d = e / H, hh = e - d * H;
+        slab[oWs + ((g0 + gi) * K + k) * H + hh] = sacc;
+        continue;
+      }
+      int e = o - t1, per = DGS * H;
+      if (o >= t2) { e = o - t2; per = DGS; }
+      if (o >= t3) e = o - t3;
+      const int gi = e / per, rem = e - gi * per, base = gi * NR, g = g0 + gi;
+      const int o0 = a.group_off[g], dg = a.group_off[g + 1] - o0;
+      if (o < t2) {
+        const int d = rem / H, hh = rem - d * H;
         if (d < dg) {
 #pragma unroll 8
           for (int n = 0; n < NR; ++n) sacc = __builtin_fmaf(gmuS[(base + n) * DGS + d], actS[(base + n) * HP + hh], sacc);
           slab[oW2 + (o0 + d) * H + hh] = sacc;
         }
-      } else if (idx < K * H + DGS * H + DGS) {
-        const int d = idx - K * H - DGS * H;
+      } else if (o < t3) {
+        const int d = rem;
         if (d < dg) {
 #pragma unroll 8
           for (int n = 0; n < NR; ++n) sacc += gmuS[(base + n) * DGS + d];
           slab[ob2 + o0 + d] = sacc;
         }
       } else {
-        const int d = idx - K * H - DGS * H - DGS;
+        const int d = rem;
         if (d < dg) {
           // L = inv sum_n [log sigma + q^2 / 2], q = (x - mu) / sigma = -(d mu) sigma / inv:
           // dL/dlog_sigma = inv e / sigma (rows - sum_n q^2), sigma = e + offset
@@ -318,10 +346,10 @@ __global__ __launch_bounds__(kSmallThreads) void small_step_kernel(SmallArgs a) 
 #pragma unroll 8
           for (int n = 0; n < NR; ++n) { const float gv = gmuS[(base + n) * DGS + d]; sacc = __builtin_fmaf(gv, gv, sacc); }
           for (int r = 0; r < RB; ++r) rows_live += (r0 + r < B) ? S : 0;
-          const float e = s_exp(pLs[o0 + d]);
-          const float sig = e + a.gen_sig_off;
+          const float e2 = s_exp(pLs[o0 + d]);
+          const float sig = e2 + a.gen_sig_off;
           const float sumq2 = sacc * ((sig / inv) * (sig / inv));
-          slab[oLs + o0 + d] = ((float)rows_live - sumq2) * (e * inv / sig);
+          slab[oLs + o0 + d] = ((float)rows_live - sumq2) * (e2 * inv / sig);
         }
       }
     }
@@ -374,17 +402,36 @@ __global__ __launch_bounds__(kSmallThreads) void small_step_kernel(SmallArgs a) 
   const int nblk = a.nblk;
   const float inv_var = 1.0f / (a.sigma_theta * a.sigma_theta);
   double th_sq = 0.0;
-  for (int i = tid; i < P32; i += kSmallThreads) {   // gradients: the workgroups' slabs added in workgroup order
-    float sacc = 0.f;
-#pragma unroll 4
-    for (int b = 0; b < nblk; ++b) sacc += __builtin_nontemporal_load(a.slab + b * P32 + i);
-    const int q = OIVAE_SEG(i);
-    if (q == 4 || q == 5) {   // lib/oivae.py:15-23: the weight prior's value and its gradient theta / sigma^2 (mu_net weights and biases)
-      const float th = Ps[i];
-      th_sq += (double)th * (double)th;
-      sacc = __builtin_fmaf(th, inv_var, sacc);
+  // gradients: the workgroups' slabs added in workgroup order; four elements x four slabs requested at a time
+  for (int i0 = tid; i0 < P32; i0 += 4 * kSmallThreads) {
+    float sacc4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < nblk; b0 += 4) {
+      float v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = i0 + u * kSmallThreads, b = b0 + j;
+          v[u][j] = (i < P32 && b < nblk) ? __builtin_nontemporal_load(a.slab + b * P32 + i) : 0.f;
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sacc4[u] += v[u][j];
     }
-    a.G0[OIVAE_FOFF(q) + i - OIVAE_OFF(q)] = sacc;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * kSmallThreads;
+      if (i >= P32) break;
+      float sacc = sacc4[u];
+      const int q = OIVAE_SEG(i);
+      if (q == 4 || q == 5) {   // lib/oivae.py:15-23: the weight prior's value and its gradient theta / sigma^2 (mu_net weights and biases)
+        const float th = Ps[i];
+        th_sq += (double)th * (double)th;
+        sacc = __builtin_fmaf(th, inv_var, sacc);
+      }
+      a.G0[OIVAE_FOFF(q) + i - OIVAE_OFF(q)] = sacc;
+    }
   }
   OIVAE_STAMP(6);
   double pen = 0.0;
@@ -418,14 +465,22 @@ __global__ __launch_bounds__(kSmallThreads) void small_step_kernel(SmallArgs a) 
   OIVAE_STAMP(7);
   if (!a.do_opt) return;
   __syncthreads();   // this workgroup's own gradient stores, read back below
-  for (int i = tid; i < oWs; i += kSmallThreads) {   // Adam over everything before Ws
-    const int q = OIVAE_SEG(i), j = OIVAE_FOFF(q) + i - OIVAE_OFF(q);
-    float* pp = a.P0 + j;
-    float* pm = a.M0 + j;
-    float* pv = a.V0 + j;
-    float pi = *pp, mi = *pm, vi = *pv;
-    adam_update_dev(pi, a.G0[j], mi, vi, a.one_minus_b1, a.b2, a.one_minus_b2, a.step_size, a.inv_bc2_sqrt, a.adam_eps);
-    *pp = pi; *pm = mi; *pv = vi;
+  for (int i0 = tid; i0 < oWs; i0 += 4 * kSmallThreads) {   // Adam over everything before Ws, four elements in flight
+    float pi[4], mi[4], vi[4], gi[4];
+    int jj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * kSmallThreads, q = OIVAE_SEG(i);
+      const bool ok = i < oWs;
+      jj[u] = ok ? OIVAE_FOFF(q) + i - OIVAE_OFF(q) : -1;
+      pi[u] = ok ? a.P0[jj[u]] : 0.f; mi[u] = ok ? a.M0[jj[u]] : 0.f; vi[u] = ok ? a.V0[jj[u]] : 0.f; gi[u] = ok ? a.G0[jj[u]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (jj[u] < 0) continue;
+      adam_update_dev(pi[u], gi[u], mi[u], vi[u], a.one_minus_b1, a.b2, a.one_minus_b2, a.step_size, a.inv_bc2_sqrt, a.adam_eps);
+      a.P0[jj[u]] = pi[u]; a.M0[jj[u]] = mi[u]; a.V0[jj[u]] = vi[u];
+    }
   }
   for (int r = tid; r < G * K; r += kSmallThreads)
     prox_row_scalar_dev<true>(a.P0 + a.foff[7], a.G0 + a.foff[7], r, H, a.neg_ws_lr, a.t, a.do_prox, a.mask, a.norms, a.tab);
