@@ -118,6 +118,10 @@ __device__ __forceinline__ float s_exp(float x) { return __builtin_amdgcn_exp2f(
 __device__ __forceinline__ float s_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 __device__ __forceinline__ float s_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(s_exp(2.0f * x) + 1.0f); }
 
+// A workgroup's gradient share goes to its slab with agent-scope stores (written through to memory as they are issued):
+// what the release fence ahead of the ticket then has to push out of this XCD's L2 is nothing, instead of the slab
+#define OIVAE_SLAB_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
 // two block-wide sums at once: wave shuffles, then the 16 waves' partials through LDS in wave order (fixed order)
 __device__ __forceinline__ void block_sum2(double& x, double& y, double* sm) {
 #pragma unroll
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_step_kernel(SmallArgs a) 
         const int gi = o / (K * H), idx = o - gi * (K * H), k = idx / H, hh = idx - k * H, base = gi * NR;
 #pragma unroll 8
         for (int n = 0; n < NR; ++n) sacc = __builtin_fmaf(zs[n * KP + k], dHS[(base + n) * HP + hh], sacc);
-        slab[oWs + ((g0 + gi) * K + k) * H + hh] = sacc;
+        OIVAE_SLAB_ST(slab + (oWs + ((g0 + gi) * K + k) * H + hh), sacc);
         continue;
       }
       int e = o - t1, per = DGS * H;
@@ -328,14 +332,14 @@ __global__ __launch_bounds__(kSmallThreads) void small_step_kernel(SmallArgs a) 
         if (d < dg) {
 #pragma unroll 8
           for (int n = 0; n < NR; ++n) sacc = __builtin_fmaf(gmuS[(base + n) * DGS + d], actS[(base + n) * HP + hh], sacc);
-          slab[oW2 + (o0 + d) * H + hh] = sacc;
+          OIVAE_SLAB_ST(slab + (oW2 + (o0 + d) * H + hh), sacc);
         }
       } else if (o < t3) {
         const int d = rem;
         if (d < dg) {
 #pragma unroll 8
           for (int n = 0; n < NR; ++n) sacc += gmuS[(base + n) * DGS + d];
-          slab[ob2 + o0 + d] = sacc;
+          OIVAE_SLAB_ST(slab + (ob2 + o0 + d), sacc);
         }
       } else {
         const int d = rem;
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_step_kernel(SmallArgs a) 
           const float e2 = s_exp(pLs[o0 + d]);
           const float sig = e2 + a.gen_sig_off;
           const float sumq2 = sacc * ((sig / inv) * (sig / inv));
-          slab[oLs + o0 + d] = ((float)rows_live - sumq2) * (e2 * inv / sig);
+          OIVAE_SLAB_ST(slab + (oLs + o0 + d), ((float)rows_live - sumq2) * (e2 * inv / sig));
         }
       }
     }
@@ -381,12 +385,12 @@ __global__ __launch_bounds__(kSmallThreads) void small_step_kernel(SmallArgs a) 
     float sacc = 0.f;
 #pragma unroll 8
     for (int r = 0; r < RB; ++r) sacc = __builtin_fmaf(pre[r * 2 * K + j], Xs[r * DP + d], sacc);
-    slab[(j < K ? oWmu + j * D : oWsig + (j - K) * D) + d] = sacc;
+    OIVAE_SLAB_ST(slab + ((j < K ? oWmu + j * D : oWsig + (j - K) * D) + d), sacc);
   }
   for (int j = tid; j < 2 * K; j += kSmallThreads) {
     float sacc = 0.f;
     for (int r = 0; r < RB; ++r) sacc += pre[r * 2 * K + j];
-    slab[(j < K ? obmu + j : obsig + (j - K))] = sacc;
+    OIVAE_SLAB_ST(slab + ((j < K ? obmu + j : obsig + (j - K))), sacc);
   }
   OIVAE_STAMP(4);
   block_sum2(kl, ll, sm);
@@ -402,22 +406,22 @@ __global__ __launch_bounds__(kSmallThreads) void small_step_kernel(SmallArgs a) 
   const int nblk = a.nblk;
   const float inv_var = 1.0f / (a.sigma_theta * a.sigma_theta);
   double th_sq = 0.0;
-  // gradients: the workgroups' slabs added in workgroup order; four elements x four slabs requested at a time
+  // gradients: the workgroups' slabs added in workgroup order; four elements x eight slabs requested at a time
   for (int i0 = tid; i0 < P32; i0 += 4 * kSmallThreads) {
     float sacc4[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int b0 = 0; b0 < nblk; b0 += 4) {
-      float v[4][4];
+    for (int b0 = 0; b0 < nblk; b0 += 8) {
+      float v[4][8];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
           const int i = i0 + u * kSmallThreads, b = b0 + j;
           v[u][j] = (i < P32 && b < nblk) ? __builtin_nontemporal_load(a.slab + b * P32 + i) : 0.f;
         }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sacc4[u] += v[u][j];
+        for (int j = 0; j < 8; ++j) sacc4[u] += v[u][j];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -442,11 +446,11 @@ __global__ __launch_bounds__(kSmallThreads) void small_step_kernel(SmallArgs a) 
     pen += (double)sqrtf(sacc);
   }
   double klt = 0.0, llt = 0.0;
-  if (tid == 0)
-    for (int b = 0; b < nblk; ++b) {
-      klt += __builtin_nontemporal_load(a.kl_part + b);
-      llt += __builtin_nontemporal_load(a.ll_part + b);
-    }
+  if (tid < 64) {   // one load per lane (nblk <= 32), then added in workgroup order through lane 0's shuffles
+    const double k0 = (tid < nblk) ? __builtin_nontemporal_load(a.kl_part + tid) : 0.0;
+    const double l0 = (tid < nblk) ? __builtin_nontemporal_load(a.ll_part + tid) : 0.0;
+    for (int b = 0; b < nblk; ++b) { klt += __shfl(k0, b); llt += __shfl(l0, b); }
+  }
   block_sum2(th_sq, pen, sm);
   const double th_tot = th_sq, pen_tot = pen;
   if (tid == 0) {   // as finalize_kernel (api.hip)
