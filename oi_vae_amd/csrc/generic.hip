@@ -804,7 +804,10 @@ DecPlan plan_decoder(const oivae_shape_t& s, int64_t N) {
   if (pl.flat) pl.chunks = 1;
   if (pl.single) {   // 64-row tiles; several workgroups per CU (their loads of X overlap) and at least one tile each
     const int64_t t64 = (N + 63) / 64;
-    int64_t cc = (1536 + s.G - 1) / s.G;
+    // as many workgroups as the chip holds at once (four per CU by registers at H <= 2, three above: 1024 / 768), not
+    // more: a second, partial round of workgroups costs a whole workgroup time (MEG-like decoder: 74 us at 1536
+    // workgroups, 68 at 1024, 78 at 768 and at 2816)
+    int64_t cc = ((s.H <= 2 ? 1024 : 768) + s.G - 1) / s.G;
     if (cc > t64) cc = t64;
     if (cc < 1) cc = 1;
     if ((int64_t)s.G * cc > kMaxPartials) cc = kMaxPartials / s.G > 0 ? kMaxPartials / s.G : 1;
