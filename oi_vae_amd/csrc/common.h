@@ -202,5 +202,6 @@ int noalloc_scratch_setup(int device);
 struct SlabSegs { float* dst[6]; int64_t off[6], n[6]; };
 int launch_slab_reduce(const float* slab, const DecLayout& L, int chunks, const oivae_tensors_t* grads, hipStream_t st);
 void launch_partial_sum(const float* parts, int64_t P, int64_t n, int chunks, float* dst, hipStream_t st);
+void launch_partial_sum2(const float* parts, int64_t P, int64_t n, int chunks, float* dst0, float* dst1, hipStream_t st);
 
 }  // namespace oivae

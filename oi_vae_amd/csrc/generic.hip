@@ -549,6 +549,18 @@ void launch_partial_sum(const float* parts, int64_t P, int64_t n, int chunks, fl
   hipLaunchKernelGGL(slab_reduce, dim3((unsigned)blocks, 1), dim3(256), 0, st, parts, P, chunks, sg);
 }
 
+// two consecutive segments of n floats each (the encoder backward's two heads): dst0[i] = sum_c parts[c * P + i],
+// dst1[i] = sum_c parts[c * P + n + i], one launch
+void launch_partial_sum2(const float* parts, int64_t P, int64_t n, int chunks, float* dst0, float* dst1, hipStream_t st) {
+  if (n == 0) return;
+  SlabSegs sg = {};
+  sg.dst[0] = dst0; sg.off[0] = 0; sg.n[0] = n;
+  sg.dst[1] = dst1; sg.off[1] = n; sg.n[1] = n;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(slab_reduce, dim3((unsigned)blocks, 2), dim3(256), 0, st, parts, P, chunks, sg);
+}
+
 int launch_slab_reduce(const float* slab, const DecLayout& L, int chunks, const oivae_tensors_t* grads, hipStream_t st) {
   SlabSegs sg;
   float* dst[6] = {grads->gen_W1, grads->gen_b1, grads->gen_W2, grads->gen_b2, grads->log_sigma, grads->Ws};

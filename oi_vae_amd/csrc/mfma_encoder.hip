@@ -366,8 +366,7 @@ static int launch_bwd(const float* X, const float* dpre, int64_t B, int D, int K
   if (nz > 1) {
     hipLaunchKernelGGL((enc_bwd_gemm<TJ, ND>), grid, dim3(256), lds, st, X, dpre, B, D, K, part, part + (int64_t)K * D, per, JD);
     OIVAE_LAUNCH_CHECK();
-    launch_partial_sum(part, JD, (int64_t)K * D, nz, dWmu, st);
-    launch_partial_sum(part + (int64_t)K * D, JD, (int64_t)K * D, nz, dWsig, st);
+    launch_partial_sum2(part, JD, (int64_t)K * D, nz, dWmu, dWsig, st);   // both heads' images in one launch
   } else {
     hipLaunchKernelGGL((enc_bwd_gemm<TJ, ND>), grid, dim3(256), lds, st, X, dpre, B, D, K, dWmu, dWsig, T, (int64_t)0);
   }
