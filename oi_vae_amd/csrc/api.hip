@@ -271,9 +271,15 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double* kl, int n_k
   __shared__ double sm[4][256];
   const double* src[4] = {kl, ll, th, pen};
   const int cnt[4] = {n_kl, n_ll, n_th, n_pen};
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < 4; ++q) {   // eight loads in flight per thread (one by one, each cost a trip to memory); same order of addition
     double a = 0.0;
-    for (int i = threadIdx.x; i < cnt[q]; i += 256) a += src[q][i];
+    for (int i0 = threadIdx.x; i0 < cnt[q]; i0 += 8 * 256) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (i0 + u * 256 < cnt[q]) ? src[q][i0 + u * 256] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
     sm[q][threadIdx.x] = a;
   }
   __syncthreads();

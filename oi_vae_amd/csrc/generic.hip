@@ -99,9 +99,16 @@ __global__ __launch_bounds__(256) void enc_fwd_epilogue(
     const int64_t b = i / K;
     const int k = (int)(i - b * K);
     float pm = pre[b * J + k], pa = pre[b * J + K + k];
-    for (int sp = 1; sp < nsplit; ++sp) {  // split-K partial images, summed in index order
-      pm += pre[(int64_t)sp * B * J + b * J + k];
-      pa += pre[(int64_t)sp * B * J + b * J + K + k];
+    for (int s0 = 1; s0 < nsplit; s0 += 7) {  // split-K partial images, summed in index order; requested seven at a time
+      float vm[7], va[7];
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        const bool ok = s0 + u < nsplit;
+        vm[u] = ok ? pre[(int64_t)(s0 + u) * B * J + b * J + k] : 0.f;
+        va[u] = ok ? pre[(int64_t)(s0 + u) * B * J + b * J + K + k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 7; ++u) { pm += vm[u]; pa += va[u]; }
     }
     const float mu = pm + bmu[k];
     const float a = pa + bsig[k];
@@ -532,9 +539,15 @@ __global__ __launch_bounds__(256) void slab_reduce(const float* __restrict__ sla
   const int64_t seg_off = sg.off[q], seg_n = sg.n[q];
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < seg_n; i += stride) {
+  for (; i < seg_n; i += stride) {   // eight chunks requested at a time (one by one, each cost a trip to memory); same order of addition
     float acc = 0.f;
-    for (int c = 0; c < chunks; ++c) acc += slab[(int64_t)c * P + seg_off + i];
+    for (int c0 = 0; c0 < chunks; c0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (c0 + u < chunks) ? slab[(int64_t)(c0 + u) * P + seg_off + i] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
     dst[i] = acc;
   }
 }
