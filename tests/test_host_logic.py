@@ -226,3 +226,32 @@ def test_c_abi_header_is_plain_c(tmp_path):
   inc = os.path.join(root, "include")
   subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], check=True)
   subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)], check=True)
+
+
+def test_dz_layout_follows_the_padded_decoder_rule():
+  """`oivae_dz_layout` (host logic, no GPU call): two-layer generators up to 64 wide with one output width take the
+  matrix decoder (dz transposed, 1) -- always when every dimension is 32 or 64, otherwise when the padded launch pays:
+  K H + H M + M D_g >= 1536 per group or S B G >= 524288 row-groups (csrc/common.h kPadMinWork / kPadMinRowGroups,
+  measured by tools/narrow_dims.py); ragged groups, widths above 64, a D_g that is no multiple of 4 and single-layer
+  generators keep [N, K] (0)."""
+  import ctypes
+  from oi_vae_amd import _lib
+  L = _lib.load()
+  offs = (ctypes.c_int32 * 2)(0, 1)   # the layout rule never reads the offsets; the pointer only has to be non-null
+
+  def layout(K, H, M, dg, G, B, S=1, gen="mlp", uniform=True):
+    sh = _lib.Shape(D=dg * G, K=K, G=G, H=H, M=M, gen_type=_lib.GEN_TYPES[gen], max_group_dim=dg,
+                    uniform_group_dim=dg if uniform else 0, group_off=ctypes.cast(offs, ctypes.c_void_p).value)
+    return L.oivae_dz_layout(ctypes.byref(sh), B, S)
+
+  assert layout(64, 64, 64, 64, 4, 64) == 1
+  assert layout(32, 64, 32, 32, 3, 1) == 1                  # any mix of 32 and 64, whatever the size
+  assert layout(40, 24, 56, 44, 5, 64) == 1                 # narrow, enough work per group (4768)
+  assert layout(16, 16, 16, 16, 8, 256) == 0                # narrow, 768 < 1536, 2048 row-groups
+  assert layout(16, 16, 16, 16, 256, 2048) == 1             # the same shape at 524288 row-groups
+  assert layout(16, 16, 16, 16, 256, 1024, S=2) == 1        # ... counted in decoder rows S B
+  assert layout(16, 16, 16, 16, 256, 2047) == 0
+  assert layout(64, 64, 64, 42, 4, 4096) == 0               # D_g no multiple of 4: X is read 16 bytes per lane
+  assert layout(64, 64, 96, 64, 4, 4096) == 0               # wider than 64
+  assert layout(64, 64, 64, 64, 4, 4096, uniform=False) == 0   # ragged groups
+  assert layout(10, 1, 0, 64, 4, 4096, gen="linear") == 0   # single-layer generators
